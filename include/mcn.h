@@ -1,0 +1,143 @@
+/*
+ * mcn.h -- C ABI of libmcn_hip.so, the MI355X (gfx950) implementation of the
+ * ModelCrowdNav data-parallel rollout hot path.
+ *
+ * The reference has no FFI of its own for this path: its boundary is three duck-typed
+ * Python protocols (gym.Env, Policy, world-model callable) plus one native module, rvo2
+ * (SURVEY.md section 8b).  Each entry point below names the reference interface it
+ * replaces.  All pointers are DEVICE pointers into caller-owned HBM buffers unless
+ * marked host; every call is stream-ordered on `stream` (a hipStream_t passed as
+ * void*), performs no allocation and no synchronisation, and returns 0 on success or a
+ * negative MCN_E* code.  No torch types appear in any signature.
+ *
+ * Buffer conventions (E environments, N humans, row-major, env-major):
+ *   double2-packed arrays are [E*N][2] or [E][2] doubles, 16-byte aligned.
+ *   hpos  (px,py)   hvel (vx,vy)   hgoal (gx,gy)   hattr (radius, v_pref)     [E*N][2]
+ *   rpos  (px,py)   rvel (vx,vy)   rgoal (gx,gy)   rattr (radius, v_pref)     [E][2]
+ *   rtheta, gtime                                                             [E]
+ * The observation the reference returns from step()/reset() -- a list of
+ * ObservableState(px,py,vx,vy,radius), crowd_sim/envs/utils/state.py:27-43 -- is
+ * (hpos, hvel, hattr[:,0]) and is therefore never copied.
+ */
+#ifndef MCN_H_
+#define MCN_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCN_OK            0
+#define MCN_EINVAL      (-1)   /* bad shape / null pointer / unsupported N */
+#define MCN_ELAUNCH     (-2)   /* hipLaunchKernel reported an error        */
+
+#define MCN_MAX_HUMANS   32    /* humans per environment (one wavefront holds >= 2 envs) */
+#define MCN_MAX_LINES    10    /* ORCA maxNeighbors ceiling handled on device            */
+
+/* info codes: crowd_sim/envs/utils/info.py:1-38 */
+enum { MCN_INFO_NOTHING = 0, MCN_INFO_DANGER = 1, MCN_INFO_REACHGOAL = 2, MCN_INFO_COLLISION = 3, MCN_INFO_TIMEOUT = 4 };
+/* how humans choose their velocity */
+enum { MCN_HUMANS_ORCA = 0,     /* crowd_sim/envs/policy/orca.py:82-132            */
+       MCN_HUMANS_LINEAR = 1,   /* crowd_sim/envs/policy/linear.py:15-22           */
+       MCN_HUMANS_GIVEN = 2 };  /* model_crowd_sim.py:347 step(new_v=...) / world model output */
+enum { MCN_KIN_HOLONOMIC = 0, MCN_KIN_UNICYCLE = 1 };
+
+/* Scalar configuration: env.config [env]/[reward] + orca.py:60-66 + robot flags. */
+typedef struct mcn_env_cfg {
+    double time_step;                  /* env.config:3   */
+    double time_limit;                 /* env.config:2   */
+    double success_reward;             /* env.config:10  */
+    double collision_penalty;          /* env.config:11  */
+    double discomfort_dist;            /* env.config:12  */
+    double discomfort_penalty_factor;  /* env.config:13  */
+    double orca_safety_space;          /* orca.py:59     */
+    float  orca_neighbor_dist;         /* orca.py:60     */
+    float  orca_time_horizon;          /* orca.py:62     */
+    int32_t orca_max_neighbors;        /* orca.py:61 (<= MCN_MAX_LINES) */
+    int32_t robot_visible;             /* humans see the robot, crowd_sim.py:340 */
+    int32_t human_policy;              /* MCN_HUMANS_*   */
+    int32_t robot_kinematics;          /* MCN_KIN_*      */
+    int32_t count_hh;                  /* crowd_sim.py:368-376 (CrowdSim yes, ModelCrowdSim no) */
+    int32_t track_human_times;         /* crowd_sim.py:418-421 */
+} mcn_env_cfg;
+
+/* Device state of E environments (all device pointers, caller-owned). */
+typedef struct mcn_env_state {
+    double *hpos, *hvel, *hgoal, *hattr;       /* [E*N][2] */
+    double *rpos, *rvel, *rgoal, *rattr;       /* [E][2]   */
+    double *rtheta;                            /* [E]      */
+    double *gtime;                             /* [E]  CrowdSim.global_time */
+    double *human_times;                       /* [E*N] or NULL */
+} mcn_env_state;
+
+/* Per-step outputs (device pointers). */
+typedef struct mcn_env_out {
+    double  *reward;      /* [E] */
+    double  *dmin;        /* [E] min boundary distance robot-human over the step (inf if N==0) */
+    uint8_t *done;        /* [E] */
+    uint8_t *info;        /* [E] MCN_INFO_* */
+    int32_t *hh_count;    /* [E] human-human overlaps (reference only logs them) */
+    double  *human_act;   /* [E*N][2] velocity each human chose, or NULL */
+    double  *nobs_pos;    /* [E*N][2] next observable positions  (update == 0 only) */
+    double  *nobs_vel;    /* [E*N][2] next observable velocities (update == 0 only) */
+} mcn_env_out;
+
+/*
+ * Optional fused bookkeeping of Explorer.run_k_episodes (crowd_nav/utils/explorer.py:54-125)
+ * and vector-env style auto-reset.  Any pointer may be NULL to disable that part.
+ */
+typedef struct mcn_rollout {
+    /* discounted return: sum_t disc_table[t] * r_t, disc_table[t] = pow(gamma, t*dt*v_pref) (explorer.py:124) */
+    const double *disc_table;  int32_t disc_len;
+    double  *ep_return;        /* [E] running sum       */
+    int32_t *ep_steps;         /* [E] steps taken in the running episode */
+    /* record of the most recently finished episode per env */
+    double  *fin_return;       /* [E] */
+    double  *fin_time;         /* [E] env.global_time at the end (explorer.py:95,99) */
+    uint8_t *fin_info;         /* [E] */
+    int32_t *fin_count;        /* [E] episodes finished so far */
+    /* auto-reset from a pool of host-generated scenarios (bit-exact CrowdSim.reset output) */
+    const double *pool_hpos, *pool_hgoal, *pool_hattr;   /* [P*N][2] */
+    const double *pool_hvel;                             /* [P*N][2] or NULL (zeros) */
+    int32_t pool_size;
+    int32_t *next_case;        /* [E] index into the pool used at the next reset; advanced by case_stride mod pool_size */
+    int32_t case_stride;
+    double  robot_start[2], robot_goal[2], robot_theta0;  /* crowd_sim.py:284 */
+} mcn_rollout;
+
+/*
+ * mcn_env_step -- one batched CrowdSim.step / ModelCrowdSim.step.
+ * Replaces: crowd_sim/envs/crowd_sim.py:331-434 (step, update=True/False),
+ *           crowd_sim/envs/crowd_sim.py:325-329 (onestep_lookahead),
+ *           crowd_sim/envs/model_crowd_sim.py:347-441,
+ *           and the per-human rvo2 round trip of crowd_sim/envs/policy/orca.py:82-132.
+ * actions: [E][2] (vx,vy) holonomic or (v,r) unicycle.  given_v: [E*N][2] or NULL.
+ * update != 0 advances state in place; update == 0 leaves state untouched and fills nobs_*.
+ * roll may be NULL.
+ */
+int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *actions,
+                 const double *given_v, const mcn_env_out *out, const mcn_rollout *roll,
+                 int32_t E, int32_t N, int32_t update, void *stream);
+
+/*
+ * mcn_orca_batch -- ORCA velocity for B independent agents, each with up to M candidate
+ * neighbours (float32, RVO2 semantics).  Replaces the rvo2.PyRVOSimulator
+ * addAgent / setAgent... / doStep / getAgentVelocity(0) sequence of orca.py:95-129 for arbitrary agents
+ * (used for an ORCA-driven robot, test.py:52 --policy orca).
+ * self:   [B][8] float  (px,py,vx,vy,radius,max_speed,pref_x,pref_y)
+ * others: [B][M][5] float (px,py,vx,vy,radius); n_other: [B] int32 valid counts
+ * out:    [B][2] float new velocity
+ */
+int mcn_orca_batch(const float *self, const float *others, const int32_t *n_other, float *out,
+                   int32_t B, int32_t M, float neighbor_dist, int32_t max_neighbors,
+                   float time_horizon, float time_step, void *stream);
+
+/* Library self-description (host). */
+const char *mcn_version(void);
+int mcn_device_arch(char *buf, int32_t len);   /* fills e.g. "gfx950"; needs a GPU */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCN_H_ */

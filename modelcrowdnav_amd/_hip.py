@@ -1,0 +1,99 @@
+"""ctypes binding of libmcn_hip.so (C ABI: include/mcn.h).
+
+The library is the product: there is no CPU fallback.  If it is missing, importing this
+module raises, and every env / policy entry point above it fails with it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmcn_hip.so")
+
+MCN_OK, MCN_EINVAL, MCN_ELAUNCH = 0, -1, -2
+MAX_HUMANS, MAX_LINES = 32, 10
+INFO_NOTHING, INFO_DANGER, INFO_REACHGOAL, INFO_COLLISION, INFO_TIMEOUT = range(5)
+HUMANS_ORCA, HUMANS_LINEAR, HUMANS_GIVEN = range(3)
+KIN_HOLONOMIC, KIN_UNICYCLE = 0, 1
+
+_vp, _d, _f, _i = C.c_void_p, C.c_double, C.c_float, C.c_int32
+
+
+class EnvCfg(C.Structure):
+    _fields_ = [
+        ("time_step", _d), ("time_limit", _d), ("success_reward", _d), ("collision_penalty", _d),
+        ("discomfort_dist", _d), ("discomfort_penalty_factor", _d), ("orca_safety_space", _d),
+        ("orca_neighbor_dist", _f), ("orca_time_horizon", _f),
+        ("orca_max_neighbors", _i), ("robot_visible", _i), ("human_policy", _i),
+        ("robot_kinematics", _i), ("count_hh", _i), ("track_human_times", _i),
+    ]
+
+
+class EnvState(C.Structure):
+    _fields_ = [(k, _vp) for k in ("hpos", "hvel", "hgoal", "hattr", "rpos", "rvel", "rgoal", "rattr",
+                                   "rtheta", "gtime", "human_times")]
+
+
+class EnvOut(C.Structure):
+    _fields_ = [(k, _vp) for k in ("reward", "dmin", "done", "info", "hh_count", "human_act", "nobs_pos", "nobs_vel")]
+
+
+class Rollout(C.Structure):
+    _fields_ = [
+        ("disc_table", _vp), ("disc_len", _i),
+        ("ep_return", _vp), ("ep_steps", _vp),
+        ("fin_return", _vp), ("fin_time", _vp), ("fin_info", _vp), ("fin_count", _vp),
+        ("pool_hpos", _vp), ("pool_hgoal", _vp), ("pool_hattr", _vp), ("pool_hvel", _vp),
+        ("pool_size", _i), ("next_case", _vp), ("case_stride", _i),
+        ("robot_start", _d * 2), ("robot_goal", _d * 2), ("robot_theta0", _d),
+    ]
+
+
+class McnError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "modelcrowdnav_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C modelcrowdnav_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.mcn_version.restype = C.c_char_p
+    lib.mcn_device_arch.argtypes = [C.c_char_p, _i]
+    lib.mcn_env_step.argtypes = [C.POINTER(EnvCfg), C.POINTER(EnvState), _vp, _vp, C.POINTER(EnvOut),
+                                 C.POINTER(Rollout), _i, _i, _i, _vp]
+    lib.mcn_env_step.restype = C.c_int
+    lib.mcn_orca_batch.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _f, _f, _vp]
+    lib.mcn_orca_batch.restype = C.c_int
+    return lib
+
+
+lib = _load()
+
+# every symbol include/mcn.h declares; tests/test_abi.py checks the .so exports each one
+EXPORTED = ["mcn_version", "mcn_device_arch", "mcn_env_step", "mcn_orca_batch"]
+
+
+def check(rc, what):
+    if rc != MCN_OK:
+        raise McnError("%s failed with code %d (%s)" % (what, rc, {-1: "MCN_EINVAL", -2: "MCN_ELAUNCH"}.get(rc, "?")))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def version():
+    return lib.mcn_version().decode()
+
+
+def device_arch():
+    buf = C.create_string_buffer(64)
+    check(lib.mcn_device_arch(buf, 64), "mcn_device_arch")
+    return buf.value.decode()

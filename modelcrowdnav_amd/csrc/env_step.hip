@@ -1,0 +1,307 @@
+// env_step.hip -- fused batched CrowdSim.step for gfx950 (MI355X).
+//
+// One launch does, for every environment of the batch:
+//   K1  human velocity choice: ORCA solve per human        (crowd_sim.py:336-342, orca.py:82-132)
+//   K2  robot-human swept-circle test + min distance,       (crowd_sim.py:345-365, utils.py:4-26)
+//       human-human overlap count                           (crowd_sim.py:368-376)
+//   K3  goal test, reward ladder, integration, look-ahead   (crowd_sim.py:379-432, agent.py:63-74,110-138)
+//       + optional Explorer bookkeeping / auto-reset         (explorer.py:54-125)
+//
+// Mapping (wave64): lane = (env-in-wave g, human h), G = 64 / N environments per wavefront,
+// so one global_load_dwordx4 per lane per field reads a contiguous run of the [E*N][2] arrays.
+// Neighbour state is staged once in LDS (float4 pos/vel for the float32 ORCA solve, double2
+// for the float64 overlap test); the per-env min-distance / overlap-count reductions are
+// wavefront shuffles over the N lanes of a group; lane h == 0 of each group owns the robot
+// and the per-env scalars.  Groups never straddle wavefronts, so no cross-wave traffic
+// exists and workgroup size is only a dispatch-granularity knob (64 for small batches to
+// spread over all 256 CUs, 256 for large ones).
+//
+// Algorithmic HBM bytes per env-step: (17 + 12 N) * 8 + 6  -> 622 B at N = 5.
+// All float64 arithmetic is in the reference's operation order with contraction off;
+// norm2() uses one explicit fma because numpy.linalg.norm's 2-element dot does.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mcn.h"
+#include "orca_device.hpp"
+#include "env_step_params.hpp"
+
+namespace mcn {
+
+__device__ __forceinline__ double norm2(double x0, double x1) { return sqrt(fma(x1, x1, x0 * x0)); }
+
+// crowd_sim/envs/utils/utils.py:4-26 with (x3, y3) = (0, 0), the env's only call shape
+__device__ __forceinline__ double p2s_origin(double x1, double y1, double x2, double y2)
+{
+    const double px = x2 - x1, py = y2 - y1;
+    if (px == 0 && py == 0) return norm2(0.0 - x1, 0.0 - y1);
+    double u = ((0.0 - x1) * px + (0.0 - y1) * py) / (px * px + py * py);
+    if (u > 1) u = 1; else if (u < 0) u = 0;
+    const double x = x1 + u * px, y = y1 + u * py;
+    return norm2(x - 0.0, y - 0.0);
+}
+
+// Python's float % for a positive divisor
+__device__ __forceinline__ double pymod(double a, double m)
+{
+    double r = fmod(a, m);
+    if (r != 0 && r < 0) r += m;
+    return r;
+}
+
+struct GroupCand {
+    const float4 *sAg; const float *sRad;   // block-level staged humans
+    float4 rob; float rob_rad;              // robot as seen by humans (if visible)
+    int gbase, h, nh;                       // tid of human 0 of my env, my index, humans-as-candidates count (N-1)
+    __device__ __forceinline__ void fetch(int c, float4 &pv, float &rad) const {
+        if (c < nh) { const int j = c + (c >= h); pv = sAg[gbase + j]; rad = sRad[gbase + j]; }
+        else { pv = rob; rad = rob_rad; }
+    }
+};
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void env_step_kernel(const StepParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // carve (all offsets multiples of 16 B)
+    float4  *sL      = reinterpret_cast<float4 *>(smem);                       // [nl_cap][BLOCK]
+    float4  *sAgF    = sL + (size_t)p.nl_cap * BLOCK;                          // [BLOCK]
+    double2 *sPosD   = reinterpret_cast<double2 *>(sAgF + BLOCK);              // [BLOCK]
+    double2 *sRobPos = sPosD + BLOCK;                                          // [BLOCK] per env slot
+    double2 *sRobAct = sRobPos + BLOCK;                                        // [BLOCK]
+    float4  *sRobF   = reinterpret_cast<float4 *>(sRobAct + BLOCK);            // [BLOCK]
+    double  *sRadD   = reinterpret_cast<double *>(sRobF + BLOCK);              // [BLOCK]
+    double  *sRobRad = sRadD + BLOCK;                                          // [BLOCK]
+    float   *sRadF   = reinterpret_cast<float *>(sRobRad + BLOCK);             // [BLOCK]
+    float   *sRobRadF = sRadF + BLOCK;                                         // [BLOCK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int N = p.N, G = p.G;
+    const int g = lane / N;
+    const int h = lane - g * N;
+    const int slot = wave * G + g;                          // env slot inside the block
+    const long e = (long)blockIdx.x * ((BLOCK / 64) * G) + slot;
+    const bool active = (g < G) && (e < p.E);
+    const bool leader = active && (h == 0);
+    const long a = active ? e * N + h : 0;
+    const int gbase = tid - h;
+    const mcn_env_cfg &c = p.cfg;
+    const double dt = c.time_step;
+
+    // ---- coalesced agent-state loads (16 B per lane per field) ----
+    double2 pos = make_double2(0, 0), vel = pos, goal = pos, attr = pos;
+    if (active) {
+        pos  = reinterpret_cast<const double2 *>(p.st.hpos)[a];
+        vel  = reinterpret_cast<const double2 *>(p.st.hvel)[a];
+        goal = reinterpret_cast<const double2 *>(p.st.hgoal)[a];
+        attr = reinterpret_cast<const double2 *>(p.st.hattr)[a];
+    }
+    double2 rpos = make_double2(0, 0), rvel = rpos, rgoal = rpos, rattr = rpos, act = rpos;
+    double rtheta = 0, gtime = 0;
+    int next_case = 0;
+    if (leader) {
+        rpos  = reinterpret_cast<const double2 *>(p.st.rpos)[e];
+        rvel  = reinterpret_cast<const double2 *>(p.st.rvel)[e];
+        rgoal = reinterpret_cast<const double2 *>(p.st.rgoal)[e];
+        rattr = reinterpret_cast<const double2 *>(p.st.rattr)[e];
+        act   = reinterpret_cast<const double2 *>(p.actions)[e];
+        gtime = p.st.gtime[e];
+        if (c.robot_kinematics == MCN_KIN_UNICYCLE) rtheta = p.st.rtheta[e];
+        if (p.has_roll && p.roll.next_case) next_case = p.roll.next_case[e];
+    }
+    // effective robot velocity for the swept test (crowd_sim.py:350-355)
+    double2 eff = act;
+    if (leader && c.robot_kinematics == MCN_KIN_UNICYCLE) {
+        eff.x = act.x * cos(act.y + rtheta);
+        eff.y = act.x * sin(act.y + rtheta);
+    }
+
+    // ---- stage neighbour tiles in LDS ----
+    const float fpx = (float)pos.x, fpy = (float)pos.y, fvx = (float)vel.x, fvy = (float)vel.y;
+    const float frad = (float)(attr.x + 0.01 + c.orca_safety_space);
+    sAgF[tid] = make_float4(fpx, fpy, fvx, fvy);
+    sRadF[tid] = frad;
+    sPosD[tid] = pos;
+    sRadD[tid] = attr.x;
+    if (leader) {
+        sRobPos[slot] = rpos;
+        sRobAct[slot] = eff;
+        sRobRad[slot] = rattr.x;
+        sRobF[slot] = make_float4((float)rpos.x, (float)rpos.y, (float)rvel.x, (float)rvel.y);
+        sRobRadF[slot] = (float)(rattr.x + 0.01 + c.orca_safety_space);
+    }
+    __syncthreads();
+
+    // ---- K1: human action ----
+    double hax = 0, hay = 0;
+    if (active) {
+        if (c.human_policy == MCN_HUMANS_ORCA) {
+            GroupCand cand{sAgF, sRadF, make_float4(0, 0, 0, 0), 0.f, gbase, h, N - 1};
+            int ncand = N - 1;
+            if (c.robot_visible) { cand.rob = sRobF[slot]; cand.rob_rad = sRobRadF[slot]; ++ncand; }
+            float ox, oy;
+            LdsLines L{sL + tid, BLOCK};
+            orca_solve(cand, ncand, fpx, fpy, fvx, fvy, frad, (float)attr.y,
+                       (float)(goal.x - pos.x), (float)(goal.y - pos.y),
+                       c.orca_neighbor_dist, c.orca_max_neighbors, c.orca_time_horizon, (float)dt, L, ox, oy);
+            hax = (double)ox; hay = (double)oy;
+        } else if (c.human_policy == MCN_HUMANS_LINEAR) {
+            const double th = atan2(goal.y - pos.y, goal.x - pos.x);
+            hax = cos(th) * attr.y; hay = sin(th) * attr.y;
+        } else {
+            const double2 gv = reinterpret_cast<const double2 *>(p.given_v)[a];
+            hax = gv.x; hay = gv.y;
+        }
+    }
+
+    // ---- K2: swept-circle distance to the robot, overlap with later humans ----
+    double cd = INFINITY;
+    int hh = 0;
+    if (active) {
+        const double2 R = sRobPos[slot], A = sRobAct[slot];
+        const double rr = sRobRad[slot];
+        const double px = pos.x - R.x, py = pos.y - R.y;
+        const double vx = vel.x - A.x, vy = vel.y - A.y;
+        const double ex = px + vx * dt, ey = py + vy * dt;
+        cd = p2s_origin(px, py, ex, ey) - attr.x - rr;
+        if (c.count_hh) {
+            for (int j = h + 1; j < N; ++j) {
+                const double2 q = sPosD[gbase + j];
+                const double dx = pos.x - q.x, dy = pos.y - q.y;
+                const double d = sqrt(dx * dx + dy * dy) - attr.x - sRadD[gbase + j];
+                hh += (d < 0);
+            }
+        }
+    }
+    // wavefront shuffle reductions over the N lanes of the group
+    const int l0 = lane - h;
+    double dmin = INFINITY;
+    int hh_sum = 0;
+    for (int k = 0; k < N; ++k) {
+        const int src = (l0 + k) & 63;
+        const double o = __shfl(cd, src);
+        dmin = fmin(dmin, o);
+        hh_sum += __shfl(hh, src);
+    }
+
+    // ---- K3: goal test + reward ladder (leader lane) ----
+    double endx = 0, endy = 0, new_theta = rtheta, nrvx = 0, nrvy = 0;
+    double rew = 0;
+    int dn = 0, inf = MCN_INFO_NOTHING;
+    if (leader) {
+        if (c.robot_kinematics == MCN_KIN_UNICYCLE) {
+            const double th = rtheta + act.y;                       // agent.py:115-118
+            endx = rpos.x + cos(th) * act.x * dt;
+            endy = rpos.y + sin(th) * act.x * dt;
+            new_theta = pymod(rtheta + act.y, 2 * M_PI);            // agent.py:130-135
+            nrvx = act.x * cos(new_theta); nrvy = act.x * sin(new_theta);
+        } else {
+            endx = rpos.x + act.x * dt; endy = rpos.y + act.y * dt;
+            nrvx = act.x; nrvy = act.y;
+        }
+        const bool reaching = norm2(endx - rgoal.x, endy - rgoal.y) < rattr.x;
+        const bool collision = dmin < 0;
+        if (gtime >= c.time_limit - 1)      { rew = 0; dn = 1; inf = MCN_INFO_TIMEOUT; }
+        else if (collision)                 { rew = c.collision_penalty; dn = 1; inf = MCN_INFO_COLLISION; }
+        else if (reaching)                  { rew = c.success_reward; dn = 1; inf = MCN_INFO_REACHGOAL; }
+        else if (dmin < c.discomfort_dist)  { rew = (dmin - c.discomfort_dist) * c.discomfort_penalty_factor * dt; dn = 0; inf = MCN_INFO_DANGER; }
+        else                                { rew = 0; dn = 0; inf = MCN_INFO_NOTHING; }
+        p.out.reward[e] = rew;
+        p.out.dmin[e] = dmin;
+        p.out.done[e] = (uint8_t)dn;
+        p.out.info[e] = (uint8_t)inf;
+        p.out.hh_count[e] = hh_sum;
+    }
+    if (active && p.out.human_act)
+        reinterpret_cast<double2 *>(p.out.human_act)[a] = make_double2(hax, hay);
+
+    // ---- integrate / look ahead ----
+    const double npx = pos.x + hax * dt, npy = pos.y + hay * dt;
+    if (!p.update) {
+        if (active) {
+            reinterpret_cast<double2 *>(p.out.nobs_pos)[a] = make_double2(npx, npy);
+            reinterpret_cast<double2 *>(p.out.nobs_vel)[a] = make_double2(hax, hay);
+        }
+        return;
+    }
+    const bool do_reset = p.has_roll && p.roll.pool_hpos != nullptr;
+    const int dn_g = __shfl(dn, l0 & 63);
+    const double t_new = __shfl(gtime, l0 & 63) + dt;
+    const int case_g = __shfl(next_case, l0 & 63);
+    if (active) {
+        if (do_reset && dn_g) {
+            const long pa = (long)case_g * N + h;
+            reinterpret_cast<double2 *>(p.st.hpos)[a]  = reinterpret_cast<const double2 *>(p.roll.pool_hpos)[pa];
+            reinterpret_cast<double2 *>(p.st.hgoal)[a] = reinterpret_cast<const double2 *>(p.roll.pool_hgoal)[pa];
+            reinterpret_cast<double2 *>(p.st.hattr)[a] = reinterpret_cast<const double2 *>(p.roll.pool_hattr)[pa];
+            reinterpret_cast<double2 *>(p.st.hvel)[a]  = p.roll.pool_hvel
+                ? reinterpret_cast<const double2 *>(p.roll.pool_hvel)[pa] : make_double2(0, 0);
+            if (p.st.human_times) p.st.human_times[a] = 0;
+        } else {
+            reinterpret_cast<double2 *>(p.st.hpos)[a] = make_double2(npx, npy);
+            reinterpret_cast<double2 *>(p.st.hvel)[a] = make_double2(hax, hay);
+            if (c.track_human_times && p.st.human_times) {
+                // crowd_sim.py:418-421 / agent.py:137-138
+                if (p.st.human_times[a] == 0 && norm2(npx - goal.x, npy - goal.y) < attr.x)
+                    p.st.human_times[a] = t_new;
+            }
+        }
+    }
+    if (leader) {
+        if (p.has_roll) {
+            const mcn_rollout &r = p.roll;
+            if (r.ep_return) {
+                const int t = r.ep_steps[e];
+                const double ret = r.ep_return[e] + r.disc_table[t < r.disc_len ? t : r.disc_len - 1] * rew;
+                if (dn) {
+                    if (r.fin_return) r.fin_return[e] = ret;
+                    if (r.fin_time)   r.fin_time[e] = (inf == MCN_INFO_TIMEOUT) ? c.time_limit : t_new;
+                    if (r.fin_info)   r.fin_info[e] = (uint8_t)inf;
+                    if (r.fin_count)  r.fin_count[e] += 1;
+                    r.ep_return[e] = 0; r.ep_steps[e] = 0;
+                } else {
+                    r.ep_return[e] = ret; r.ep_steps[e] = t + 1;
+                }
+            }
+        }
+        if (do_reset && dn) {
+            reinterpret_cast<double2 *>(p.st.rpos)[e]  = make_double2(p.roll.robot_start[0], p.roll.robot_start[1]);
+            reinterpret_cast<double2 *>(p.st.rgoal)[e] = make_double2(p.roll.robot_goal[0], p.roll.robot_goal[1]);
+            reinterpret_cast<double2 *>(p.st.rvel)[e]  = make_double2(0, 0);
+            if (p.st.rtheta) p.st.rtheta[e] = p.roll.robot_theta0;
+            p.st.gtime[e] = 0;
+            if (p.roll.next_case) p.roll.next_case[e] = (next_case + p.roll.case_stride) % p.roll.pool_size;
+        } else {
+            reinterpret_cast<double2 *>(p.st.rpos)[e] = make_double2(endx, endy);
+            reinterpret_cast<double2 *>(p.st.rvel)[e] = make_double2(nrvx, nrvy);
+            if (c.robot_kinematics == MCN_KIN_UNICYCLE) p.st.rtheta[e] = new_theta;
+            p.st.gtime[e] = t_new;
+        }
+    }
+}
+
+static size_t step_smem_bytes(int block, int nl_cap)
+{
+    // float4 lines + float4 sAgF + double2 sPosD + double2 sRobPos + double2 sRobAct + float4 sRobF
+    // + double sRadD + double sRobRad + float sRadF + float sRobRadF
+    return (size_t)block * (16u * nl_cap + 16 + 16 + 16 + 16 + 16 + 8 + 8 + 4 + 4);
+}
+
+int launch_env_step(const StepParams &p, hipStream_t stream)
+{
+    const int waves_total = (p.E + p.G - 1) / p.G;
+    // small batches: one wavefront per workgroup so the grid covers as many CUs as possible
+    const bool small = waves_total <= 4096;
+    if (small) {
+        const size_t sm = step_smem_bytes(64, p.nl_cap);
+        hipLaunchKernelGGL(env_step_kernel<64>, dim3(waves_total), dim3(64), sm, stream, p);
+    } else {
+        const int blocks = (waves_total + 3) / 4;
+        const size_t sm = step_smem_bytes(256, p.nl_cap);
+        hipLaunchKernelGGL(env_step_kernel<256>, dim3(blocks), dim3(256), sm, stream, p);
+    }
+    return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
+}
+
+}  // namespace mcn

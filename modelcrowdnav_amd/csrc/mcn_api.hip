@@ -1,0 +1,77 @@
+// mcn_api.hip -- extern "C" entry points of libmcn_hip.so (see include/mcn.h).
+// Argument validation happens here, on the host, before any kernel is launched: a kernel
+// is never started on shapes its indexing does not assume.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include "../../include/mcn.h"
+
+#include "env_step_params.hpp"
+
+namespace mcn {
+int launch_env_step(const StepParams &p, hipStream_t stream);
+int launch_orca_batch(const float *self, const float *others, const int32_t *n_other, float *out,
+                      int B, int M, float neighbor_dist, int max_neighbors, float time_horizon, float time_step,
+                      hipStream_t stream);
+}  // namespace mcn
+
+extern "C" {
+
+const char *mcn_version(void) { return "modelcrowdnav_amd 0.1 (gfx950)"; }
+
+int mcn_device_arch(char *buf, int32_t len)
+{
+    if (!buf || len <= 0) return MCN_EINVAL;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return MCN_ELAUNCH;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return MCN_ELAUNCH;
+    strncpy(buf, prop.gcnArchName, (size_t)len - 1);
+    buf[len - 1] = 0;
+    return MCN_OK;
+}
+
+int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *actions,
+                 const double *given_v, const mcn_env_out *out, const mcn_rollout *roll,
+                 int32_t E, int32_t N, int32_t update, void *stream)
+{
+    if (!cfg || !st || !out || !actions) return MCN_EINVAL;
+    if (E <= 0 || N <= 0 || N > MCN_MAX_HUMANS) return MCN_EINVAL;
+    if (!st->hpos || !st->hvel || !st->hgoal || !st->hattr || !st->rpos || !st->rvel || !st->rgoal ||
+        !st->rattr || !st->gtime) return MCN_EINVAL;
+    if (cfg->robot_kinematics == MCN_KIN_UNICYCLE && !st->rtheta) return MCN_EINVAL;
+    if (!out->reward || !out->dmin || !out->done || !out->info || !out->hh_count) return MCN_EINVAL;
+    if (!update && (!out->nobs_pos || !out->nobs_vel)) return MCN_EINVAL;
+    if (cfg->human_policy == MCN_HUMANS_GIVEN && !given_v) return MCN_EINVAL;
+    if (cfg->human_policy < MCN_HUMANS_ORCA || cfg->human_policy > MCN_HUMANS_GIVEN) return MCN_EINVAL;
+    if (cfg->orca_max_neighbors < 0 || cfg->orca_max_neighbors > MCN_MAX_LINES) return MCN_EINVAL;
+    if (!(cfg->time_step > 0)) return MCN_EINVAL;
+    if (roll) {
+        if (roll->ep_return && (!roll->ep_steps || !roll->disc_table || roll->disc_len <= 0)) return MCN_EINVAL;
+        if (roll->pool_hpos && (!roll->pool_hgoal || !roll->pool_hattr || roll->pool_size <= 0)) return MCN_EINVAL;
+    }
+    mcn::StepParams p;
+    memset(&p, 0, sizeof(p));
+    p.cfg = *cfg; p.st = *st; p.out = *out;
+    if (roll) { p.roll = *roll; p.has_roll = 1; }
+    p.actions = actions; p.given_v = given_v;
+    p.E = E; p.N = N; p.G = 64 / N; p.update = update ? 1 : 0;
+    int ncand = N - 1 + (cfg->robot_visible ? 1 : 0);
+    int nl = ncand < cfg->orca_max_neighbors ? ncand : cfg->orca_max_neighbors;
+    if (cfg->human_policy != MCN_HUMANS_ORCA) nl = 0;
+    p.nl_cap = nl;
+    return mcn::launch_env_step(p, (hipStream_t)stream);
+}
+
+int mcn_orca_batch(const float *self, const float *others, const int32_t *n_other, float *out,
+                   int32_t B, int32_t M, float neighbor_dist, int32_t max_neighbors,
+                   float time_horizon, float time_step, void *stream)
+{
+    if (!self || !n_other || !out || B <= 0 || M < 0 || M > MCN_MAX_HUMANS) return MCN_EINVAL;
+    if (M > 0 && !others) return MCN_EINVAL;
+    if (max_neighbors < 0 || max_neighbors > MCN_MAX_LINES) return MCN_EINVAL;
+    if (!(time_horizon > 0) || !(time_step > 0)) return MCN_EINVAL;
+    return mcn::launch_orca_batch(self, others, n_other, out, B, M, neighbor_dist, max_neighbors,
+                                  time_horizon, time_step, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,435 @@
+"""CrowdSim on MI355X: E environments resident in HBM, stepped by one fused HIP kernel.
+
+Reference surface kept (crowd_sim/envs/crowd_sim.py): configure :58, set_robot :91,
+reset :261, step :331, onestep_lookahead :325, plus the attributes its callers read
+(case_size, case_counter, human_num, time_step, time_limit, global_time, humans, robot, states,
+sim_world, device, test_sim).  render / get_human_times are host-only visual tooling and are
+out of scope.
+
+  VecCrowdSim  tensors in / tensors out, E envs, SoA float64 state (layout: include/mcn.h)
+  CrowdSim     the E = 1 gym-style view returning the reference's value types
+"""
+import logging
+
+import numpy as np
+import torch
+
+from .. import _hip
+from . import scenarios as S
+from .policy.policy_factory import policy_factory
+from .utils import info as I
+from .utils.human import Human
+from .utils.state import ObservableState
+
+_UINT32_MAX = int(np.iinfo(np.uint32).max)
+
+
+class ObsBatch(object):
+    """Observation of a batch: views of the state arrays (never copied by step()).
+
+    pos, vel: [E,N,2] float64; radius: [E,N] float64 (a strided view of hattr).
+    `tensor()` materialises the reference's per-human 5-tuple layout [E,N,5]
+    (px,py,vx,vy,radius: crowd_sim/envs/utils/state.py:27-33) when a caller wants it.
+    """
+
+    def __init__(self, pos, vel, radius):
+        self.pos, self.vel, self.radius = pos, vel, radius
+
+    def tensor(self):
+        return torch.cat([self.pos, self.vel, self.radius.unsqueeze(-1)], dim=-1)
+
+    def to_states(self, e=0):
+        t = self.tensor()[e].cpu().tolist()
+        return [ObservableState(*row) for row in t]
+
+
+class VecCrowdSim(object):
+    def __init__(self, num_envs, device=None):
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.time_limit = self.time_step = None
+        self.robot = None
+        self.success_reward = self.collision_penalty = None
+        self.discomfort_dist = self.discomfort_penalty_factor = None
+        self.config = None
+        self.case_capacity = self.case_size = self.case_counter = None
+        self.randomize_attributes = None
+        self.train_val_sim = self.test_sim = None
+        self.square_width = self.circle_radius = None
+        self.human_num = None
+        self.look_ahead_in_sim = False
+        self.sim_world = None
+        self.human_policy_name = "orca"
+        self._orca = policy_factory["orca"]()      # parameter carrier (orca.py:59-66)
+        self._human_radius = self._human_v_pref = None
+        self._alloc_N = None
+        self._roll = None
+        self._keep = []       # tensors referenced by the rollout struct
+        self.count_hh = True
+        self.track_human_times = True
+        self.init_velocity = False     # ModelCrowdSim flavour sets True
+
+    # ---------------------------------------------------------------- configuration
+    def configure(self, config):
+        """crowd_sim.py:58-89.  `look_ahead_in_sim` is optional here: the reference's shipped
+        env.config lacks it although configure() requires it."""
+        self.config = config
+        self.time_limit = config.getint("env", "time_limit")
+        self.time_step = config.getfloat("env", "time_step")
+        self.randomize_attributes = config.getboolean("env", "randomize_attributes")
+        self.success_reward = config.getfloat("reward", "success_reward")
+        self.collision_penalty = config.getfloat("reward", "collision_penalty")
+        self.discomfort_dist = config.getfloat("reward", "discomfort_dist")
+        self.discomfort_penalty_factor = config.getfloat("reward", "discomfort_penalty_factor")
+        if config.get("humans", "policy") != "orca":
+            raise NotImplementedError
+        self.case_capacity = {"train": _UINT32_MAX - 2000, "val": 1000, "test": 1000}
+        self.case_size = self._case_sizes(config)
+        self.train_val_sim = config.get("sim", "train_val_sim")
+        self.test_sim = config.get("sim", "test_sim")
+        self.square_width = config.getfloat("sim", "square_width")
+        self.circle_radius = config.getfloat("sim", "circle_radius")
+        self.human_num = config.getint("sim", "human_num")
+        self.case_counter = {"train": 0, "test": 0, "val": 0}
+        self.look_ahead_in_sim = config.getboolean("env", "look_ahead_in_sim", fallback=False)
+        self._human_radius = config.getfloat("humans", "radius")
+        self._human_v_pref = config.getfloat("humans", "v_pref")
+        logging.info("human number: %d", self.human_num)
+        logging.info("%s human's radius and preferred speed",
+                     "Randomize" if self.randomize_attributes else "Not randomize")
+        logging.info("Training simulation: %s, test simulation: %s", self.train_val_sim, self.test_sim)
+        logging.info("Square width: %s, circle width: %s", self.square_width, self.circle_radius)
+
+    def _case_sizes(self, config):
+        # crowd_sim.py:71 hard-codes 100 training seeds
+        return {"train": 100, "val": config.getint("env", "val_size"), "test": config.getint("env", "test_size")}
+
+    def set_robot(self, robot):
+        self.robot = robot
+
+    # ---------------------------------------------------------------- device state
+    def _allocate(self, N):
+        E, dev, f64 = self.num_envs, self.device, torch.float64
+        z = lambda *shape, dtype=f64: torch.zeros(*shape, dtype=dtype, device=dev)
+        self.hpos, self.hvel, self.hgoal, self.hattr = z(E, N, 2), z(E, N, 2), z(E, N, 2), z(E, N, 2)
+        self.rpos, self.rvel, self.rgoal, self.rattr = z(E, 2), z(E, 2), z(E, 2), z(E, 2)
+        self.rtheta, self.gtime = z(E), z(E)
+        self.human_times = z(E, N)
+        self.reward, self.dmin = z(E), z(E)
+        self.done, self.info = z(E, dtype=torch.uint8), z(E, dtype=torch.uint8)
+        self.hh_count = z(E, dtype=torch.int32)
+        self.human_act = z(E, N, 2)
+        self.nobs_pos, self.nobs_vel = z(E, N, 2), z(E, N, 2)
+        self._alloc_N = N
+        self._st = _hip.EnvState(*[_hip.ptr(t) for t in (self.hpos, self.hvel, self.hgoal, self.hattr, self.rpos,
+                                                         self.rvel, self.rgoal, self.rattr, self.rtheta, self.gtime,
+                                                         self.human_times)])
+        self._out = _hip.EnvOut(*[_hip.ptr(t) for t in (self.reward, self.dmin, self.done, self.info, self.hh_count,
+                                                        self.human_act, self.nobs_pos, self.nobs_vel)])
+
+    def _cfg_struct(self, human_policy=None):
+        hp = {"orca": _hip.HUMANS_ORCA, "linear": _hip.HUMANS_LINEAR, "given": _hip.HUMANS_GIVEN}[
+            human_policy or self.human_policy_name]
+        kin = _hip.KIN_UNICYCLE if getattr(self.robot, "kinematics", "holonomic") == "unicycle" else _hip.KIN_HOLONOMIC
+        o = self._orca
+        return _hip.EnvCfg(self.time_step, float(self.time_limit), self.success_reward, self.collision_penalty,
+                           self.discomfort_dist, self.discomfort_penalty_factor, float(o.safety_space),
+                           float(o.neighbor_dist), float(o.time_horizon), int(o.max_neighbors),
+                           1 if self.robot.visible else 0, hp, kin,
+                           1 if self.count_hh else 0, 1 if self.track_human_times else 0)
+
+    def spec(self):
+        return S.ScenarioSpec(self.circle_radius, self.square_width, self.discomfort_dist, self._human_radius,
+                              self._human_v_pref, self.robot.radius, self.randomize_attributes, self.init_velocity)
+
+    def load_scenarios(self, scen, robot_rows=None):
+        """Upload host scenarios [E,N,9] (scenarios.py column order) and reset clocks."""
+        scen = np.asarray(scen, np.float64)
+        E, N = scen.shape[0], scen.shape[1]
+        if E != self.num_envs:
+            raise ValueError("expected %d scenarios, got %d" % (self.num_envs, E))
+        if self._alloc_N != N:
+            self._allocate(N)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        self.hpos.copy_(up(scen[:, :, [S.PX, S.PY]]))
+        self.hgoal.copy_(up(scen[:, :, [S.GX, S.GY]]))
+        self.hvel.copy_(up(scen[:, :, [S.VX, S.VY]]))
+        self.hattr.copy_(up(scen[:, :, [S.RAD, S.VPREF]]))
+        if robot_rows is None:
+            robot_rows = np.tile(self.spec().robot_row(), (E, 1))      # crowd_sim.py:284
+        robot_rows = np.asarray(robot_rows, np.float64)
+        self.rpos.copy_(up(robot_rows[:, [S.PX, S.PY]]))
+        self.rgoal.copy_(up(robot_rows[:, [S.GX, S.GY]]))
+        self.rvel.copy_(up(robot_rows[:, [S.VX, S.VY]]))
+        ra = np.stack([robot_rows[:, S.RAD], np.full(E, float(self.robot.v_pref))], 1)
+        self.rattr.copy_(up(ra))
+        self.rtheta.copy_(up(robot_rows[:, S.TH]))
+        self.gtime.zero_()
+        self.human_times.zero_()
+        self.human_num = N
+
+    # ---------------------------------------------------------------- gym surface (batched)
+    def _phase_rule(self, phase):
+        multi = bool(self.robot.policy.multiagent_training)
+        if not multi:
+            self.train_val_sim = "circle_crossing"      # crowd_sim.py:276-277
+        if phase in ("train", "val"):
+            return (self.human_num if multi else 1), self.train_val_sim
+        return self.human_num, self.test_sim
+
+    def reset(self, phase="test", test_cases=None):
+        """crowd_sim.py:261-323 for every env.  Env e takes case counter+e unless test_cases is given."""
+        if self.robot is None:
+            raise AttributeError("robot has to be set!")
+        assert phase in ["train", "val", "test"]
+        E = self.num_envs
+        if test_cases is None:
+            base = self.case_counter[phase]
+            cases = [(base + e) % self.case_size[phase] for e in range(E)]
+        else:
+            cases = [int(c) for c in (test_cases if hasattr(test_cases, "__len__") else [test_cases] * E)]
+        n, rule = self._phase_rule(phase)
+        scen = S.scenario_pool(self.spec(), phase, cases, n, rule)
+        self.load_scenarios(scen)
+        self.case_counter[phase] = (cases[-1] + 1) % self.case_size[phase]
+        return self.observation()
+
+    def observation(self):
+        return ObsBatch(self.hpos, self.hvel, self.hattr[..., 0])
+
+    def step(self, actions, update=True, given_v=None):
+        """crowd_sim.py:331-434 for every env: one mcn_env_step launch, no host sync.
+
+        actions: [E,2] float64 device tensor ((vx,vy) holonomic, (v,r) unicycle).
+        Returns (ObsBatch, reward[E] f64, done[E] u8, info[E] u8 codes) -- all device views that
+        the next step overwrites.  With update=False the ObsBatch holds the look-ahead states.
+        """
+        E, N = self.num_envs, self._alloc_N
+        if actions.dtype != torch.float64 or not actions.is_contiguous() or tuple(actions.shape) != (E, 2):
+            actions = actions.to(self.device, torch.float64).reshape(E, 2).contiguous()
+        policy = None
+        if given_v is not None:
+            policy = "given"
+            if given_v.dtype != torch.float64 or not given_v.is_contiguous():
+                given_v = given_v.to(self.device, torch.float64).contiguous()
+            if tuple(given_v.shape) != (E, N, 2):
+                raise ValueError("given_v must be [E,N,2]")
+        cfg = self._cfg_struct(policy)
+        rc = _hip.lib.mcn_env_step(cfg, self._st, _hip.ptr(actions), _hip.ptr(given_v), self._out,
+                                   self._roll if (self._roll is not None and update) else None,
+                                   E, N, 1 if update else 0, _hip.stream_ptr(self.device))
+        _hip.check(rc, "mcn_env_step")
+        if update:
+            ob = self.observation()
+        else:
+            ob = ObsBatch(self.nobs_pos, self.nobs_vel, self.hattr[..., 0])
+        return ob, self.reward, self.done, self.info
+
+    def onestep_lookahead(self, actions):
+        """crowd_sim.py:325-329 (look_ahead_in_sim=False path)."""
+        return self.step(actions, update=False)
+
+    # ---------------------------------------------------------------- fused rollout bookkeeping
+    def attach_rollout(self, gamma, pool=None, case_stride=1, first_cases=None):
+        """Enable Explorer-style return accounting (explorer.py:124) and, when `pool` ([P,N,9]
+        host scenarios) is given, in-kernel auto-reset from that HBM-resident pool."""
+        E, dev = self.num_envs, self.device
+        horizon = int(round(self.time_limit / self.time_step)) + 2
+        v_pref = float(self.robot.v_pref)
+        disc = np.array([pow(gamma, t * self.time_step * v_pref) for t in range(horizon)], np.float64)
+        t = {}
+        t["disc"] = torch.from_numpy(disc).to(dev)
+        t["ep_return"] = torch.zeros(E, dtype=torch.float64, device=dev)
+        t["ep_steps"] = torch.zeros(E, dtype=torch.int32, device=dev)
+        t["fin_return"] = torch.zeros(E, dtype=torch.float64, device=dev)
+        t["fin_time"] = torch.zeros(E, dtype=torch.float64, device=dev)
+        t["fin_info"] = torch.zeros(E, dtype=torch.uint8, device=dev)
+        t["fin_count"] = torch.zeros(E, dtype=torch.int32, device=dev)
+        r = _hip.Rollout()
+        r.disc_table, r.disc_len = _hip.ptr(t["disc"]), horizon
+        for k in ("ep_return", "ep_steps", "fin_return", "fin_time", "fin_info", "fin_count"):
+            setattr(r, k, _hip.ptr(t[k]))
+        if pool is not None:
+            pool = np.asarray(pool, np.float64)
+            P, N = pool.shape[0], pool.shape[1]
+            if N != self._alloc_N:
+                raise ValueError("pool N %d != env N %d" % (N, self._alloc_N))
+            up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            t["pool_hpos"] = up(pool[:, :, [S.PX, S.PY]]); t["pool_hgoal"] = up(pool[:, :, [S.GX, S.GY]])
+            t["pool_hattr"] = up(pool[:, :, [S.RAD, S.VPREF]]); t["pool_hvel"] = up(pool[:, :, [S.VX, S.VY]])
+            nc = np.arange(E) % P if first_cases is None else np.asarray(first_cases) % P
+            t["next_case"] = torch.from_numpy(nc.astype(np.int32)).to(dev)
+            r.pool_hpos, r.pool_hgoal = _hip.ptr(t["pool_hpos"]), _hip.ptr(t["pool_hgoal"])
+            r.pool_hattr, r.pool_hvel = _hip.ptr(t["pool_hattr"]), _hip.ptr(t["pool_hvel"])
+            r.pool_size, r.next_case, r.case_stride = P, _hip.ptr(t["next_case"]), int(case_stride)
+            rr = self.spec().robot_row()
+            r.robot_start[0], r.robot_start[1] = rr[S.PX], rr[S.PY]
+            r.robot_goal[0], r.robot_goal[1] = rr[S.GX], rr[S.GY]
+            r.robot_theta0 = rr[S.TH]
+        self._roll, self.rollout_buffers = r, t
+        return t
+
+    def detach_rollout(self):
+        self._roll, self.rollout_buffers = None, None
+
+
+class CrowdSim(object):
+    """E = 1 view with the reference's gym surface and value types.
+
+    Works for `gym.make('CrowdSim-v0')`-style callers: Explorer.run_k_episodes
+    (crowd_nav/utils/explorer.py:54,69), the policies' onestep_lookahead (cadrl.py:159,
+    multi_human_rl.py:38) and the drivers (test.py:64-72,90-95).  Every step is one
+    mcn_env_step launch plus a small device->host read-back that refreshes `humans` / `robot`.
+    """
+    metadata = {"render.modes": ["human"]}
+    _vec_cls = VecCrowdSim
+
+    def __init__(self, device=None):
+        self._vec = None
+        self._device = device
+        self.humans = None
+        self.global_time = None
+        self.human_times = None
+        self.states = None
+        self.action_values = None
+        self.attention_weights = None
+        self.device = None
+
+    # attributes the reference keeps on the env object live on the vector env
+    _FORWARD = ("time_limit", "time_step", "robot", "success_reward", "collision_penalty", "discomfort_dist",
+                "discomfort_penalty_factor", "config", "case_capacity", "case_size", "case_counter",
+                "randomize_attributes", "train_val_sim", "test_sim", "square_width", "circle_radius",
+                "human_num", "look_ahead_in_sim", "sim_world")
+
+    def __getattr__(self, name):
+        if name in CrowdSim._FORWARD:
+            v = self.__dict__.get("_vec")
+            return None if v is None else getattr(v, name)
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if name in CrowdSim._FORWARD and self.__dict__.get("_vec") is not None:
+            setattr(self._vec, name, value)
+        else:
+            object.__setattr__(self, name, value)
+
+    def _ensure_vec(self):
+        if self._vec is None:
+            object.__setattr__(self, "_vec", self._vec_cls(1, self._device))
+        return self._vec
+
+    def configure(self, config):
+        self._ensure_vec().configure(config)
+
+    def set_robot(self, robot):
+        self._ensure_vec().set_robot(robot)
+
+    # ------------------------------------------------------------------------------
+    def _new_humans(self, scen):
+        v = self._vec
+        humans = []
+        for row in scen:
+            h = Human(v.config, "humans")
+            h.set(row[S.PX], row[S.PY], row[S.GX], row[S.GY], row[S.VX], row[S.VY], row[S.TH],
+                  radius=row[S.RAD], v_pref=row[S.VPREF])
+            humans.append(h)
+        return humans
+
+    def reset(self, phase="test", test_case=None):
+        """crowd_sim.py:261-323: seeds numpy's GLOBAL stream like the reference, so policies that
+        draw from it afterwards (epsilon-greedy, multi_human_rl.py:28-30) see the same numbers."""
+        v = self._vec
+        if v is None or v.robot is None:
+            raise AttributeError("robot has to be set!")
+        assert phase in ["train", "val", "test"]
+        if test_case is not None:
+            v.case_counter[phase] = test_case
+        self.global_time = 0
+        multi = bool(v.robot.policy.multiagent_training)
+        self.human_times = [0] * (v.human_num if (phase == "test" or multi) else 1)
+        n, rule = v._phase_rule(phase)
+        robot = v.robot
+        robot.set(0, -v.circle_radius, 0, v.circle_radius, 0, 0, np.pi / 2)
+        case = v.case_counter[phase]
+        if case >= 0:
+            np.random.seed(S.SEED_OFFSET[phase] + case)
+            scen = S.generate(v.spec(), np.random, n, rule)
+            v.case_counter[phase] = (case + 1) % v.case_size[phase]
+        else:
+            assert phase == "test"
+            if case != -1:
+                raise NotImplementedError
+            r, vp = v._human_radius, v._human_v_pref      # crowd_sim.py:297-303 debug layout
+            scen = np.array([[0, -6, 0, 5, 0, 0, np.pi / 2, r, vp], [-5, -5, -5, 5, 0, 0, np.pi / 2, r, vp],
+                             [5, -5, 5, 5, 0, 0, np.pi / 2, r, vp]], np.float64)
+        self.humans = self._new_humans(scen)
+        v.load_scenarios(scen[None])
+        for agent in [robot] + self.humans:
+            agent.time_step = v.time_step
+            if agent.policy is not None:
+                agent.policy.time_step = v.time_step
+        self.states = list()
+        if hasattr(robot.policy, "action_values"):
+            self.action_values = list()
+        if hasattr(robot.policy, "get_attention_weights"):
+            self.attention_weights = list()
+        if robot.sensor != "coordinates":
+            raise NotImplementedError
+        return [h.get_observable_state() for h in self.humans]
+
+    def _push_host_state(self):
+        """Host mirrors are authoritative between steps in the E = 1 view (callers may call
+        robot.set()/human.set()): re-upload the few scalars before launching."""
+        v, r = self._vec, self._vec.robot
+        hs = self.humans
+        dev, f64 = v.device, torch.float64
+        t = lambda rows: torch.tensor(rows, dtype=f64, device=dev)
+        v.hpos.copy_(t([[h.px, h.py] for h in hs]).view(1, -1, 2))
+        v.hvel.copy_(t([[h.vx, h.vy] for h in hs]).view(1, -1, 2))
+        v.hgoal.copy_(t([[h.gx, h.gy] for h in hs]).view(1, -1, 2))
+        v.hattr.copy_(t([[h.radius, h.v_pref] for h in hs]).view(1, -1, 2))
+        v.rpos.copy_(t([[r.px, r.py]])); v.rvel.copy_(t([[r.vx, r.vy]]))
+        v.rgoal.copy_(t([[r.gx, r.gy]])); v.rattr.copy_(t([[r.radius, r.v_pref]]))
+        v.rtheta.copy_(t([r.theta])); v.gtime.copy_(t([self.global_time]))
+        if len(self.human_times) == len(hs):
+            v.human_times.copy_(t([self.human_times]))
+
+    def _action_tensor(self, action):
+        return torch.tensor([[action[0], action[1]]], dtype=torch.float64, device=self._vec.device)
+
+    def onestep_lookahead(self, action):
+        return self.step(action, update=False)
+
+    def step(self, action, update=True):
+        """crowd_sim.py:331-434."""
+        v = self._vec
+        robot = v.robot
+        self._push_host_state()
+        track = len(self.human_times) == len(self.humans)
+        v.track_human_times = track
+        ob, reward, done, info = v.step(self._action_tensor(action), update=update)
+        pos, vel = ob.pos[0].cpu().tolist(), ob.vel[0].cpu().tolist()
+        reward, done, code = float(reward.item()), bool(done.item()), int(info.item())
+        info_obj = I.from_code(code, float(v.dmin.item()))
+        if update:
+            self.states.append([robot.get_full_state(), [h.get_full_state() for h in self.humans]])
+            if hasattr(robot.policy, "action_values"):
+                self.action_values.append(robot.policy.action_values)
+            if hasattr(robot.policy, "get_attention_weights"):
+                self.attention_weights.append(robot.policy.get_attention_weights())
+            rp, rv = v.rpos[0].cpu().tolist(), v.rvel[0].cpu().tolist()
+            robot.px, robot.py, robot.vx, robot.vy = rp[0], rp[1], rv[0], rv[1]
+            if robot.kinematics == "unicycle":
+                robot.theta = float(v.rtheta.item())
+            for h, p, w in zip(self.humans, pos, vel):
+                h.px, h.py, h.vx, h.vy = p[0], p[1], w[0], w[1]
+            self.global_time = float(v.gtime.item())
+            if track:
+                self.human_times = v.human_times[0].cpu().tolist()
+            out = [h.get_observable_state() for h in self.humans]
+        else:
+            out = [ObservableState(p[0], p[1], w[0], w[1], h.radius) for h, p, w in zip(self.humans, pos, vel)]
+        return out, reward, done, info_obj
+
+    def render(self, mode="human", output_file=None, render_weight=False):
+        raise NotImplementedError("render is matplotlib host tooling, out of scope for this build (SURVEY.md 2)")

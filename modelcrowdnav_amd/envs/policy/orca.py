@@ -1,0 +1,60 @@
+"""ORCA policy object (reference: crowd_sim/envs/policy/orca.py:7-132).
+
+For the env's own humans this class is only a parameter carrier: VecCrowdSim reads
+neighbor_dist / max_neighbors / time_horizon / safety_space from it and the solve runs fused
+inside env_step.hip.  `predict()` serves agents outside that kernel (the ORCA-driven robot of
+`test.py --policy orca`): one mcn_orca_batch launch replaces the rvo2 simulator round trip.
+"""
+import numpy as np
+
+from .policy import Policy
+from ..utils.action import ActionXY
+
+
+class ORCA(Policy):
+    def __init__(self):
+        super().__init__()
+        self.name = "ORCA"
+        self.trainable = False
+        self.multiagent_training = None
+        self.kinematics = "holonomic"
+        self.safety_space = 0
+        self.neighbor_dist = 10
+        self.max_neighbors = 10
+        self.time_horizon = 5
+        self.time_horizon_obst = 5
+        self.radius = 0.3
+        self.max_speed = 1
+        self.sim = None          # kept for attribute compatibility; no simulator object exists here
+        self._bufs = None
+
+    def configure(self, config):
+        return
+
+    def set_phase(self, phase):
+        return
+
+    def predict(self, state):
+        import torch
+        from ... import _hip
+        me, others = state.self_state, state.human_states
+        m = len(others)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        # float32 conversion happens exactly where rvo2's Cython layer did it (orca.py:99-126)
+        self_row = np.array([me.px, me.py, me.vx, me.vy, me.radius + 0.01 + self.safety_space, me.v_pref,
+                             me.gx - me.px, me.gy - me.py], dtype=np.float64).astype(np.float32)
+        oth = np.zeros((max(m, 1), 5), np.float32)
+        for k, o in enumerate(others):
+            oth[k] = np.array([o.px, o.py, o.vx, o.vy, o.radius + 0.01 + self.safety_space],
+                              dtype=np.float64).astype(np.float32)
+        d_self = torch.from_numpy(self_row).to(dev)
+        d_oth = torch.from_numpy(oth).to(dev)
+        d_n = torch.tensor([m], dtype=torch.int32, device=dev)
+        d_out = torch.empty(2, dtype=torch.float32, device=dev)
+        _hip.check(_hip.lib.mcn_orca_batch(_hip.ptr(d_self), _hip.ptr(d_oth), _hip.ptr(d_n), _hip.ptr(d_out),
+                                           1, max(m, 1), float(self.neighbor_dist), int(self.max_neighbors),
+                                           float(self.time_horizon), float(self.time_step), _hip.stream_ptr(dev)),
+                   "mcn_orca_batch")
+        v = d_out.cpu().numpy()
+        self.last_state = state
+        return ActionXY(float(v[0]), float(v[1]))

@@ -1,0 +1,99 @@
+"""Shared test plumbing: build envs, move state between the oracle's EnvState and device tensors."""
+import numpy as np
+
+from oracle import cport
+
+
+def random_state(rng, E, N, spread=4.0, crowded_frac=0.3, randomize=False):
+    """A batch of plausible mid-episode states (float64) as an oracle EnvState."""
+    st = cport.EnvState(E, N)
+    st.rpx[:] = rng.uniform(-spread, spread, E); st.rpy[:] = rng.uniform(-spread, spread, E)
+    st.rvx[:] = rng.uniform(-1, 1, E); st.rvy[:] = rng.uniform(-1, 1, E)
+    near = rng.uniform(size=E) < 0.15
+    st.rgx[:] = np.where(near, st.rpx + rng.uniform(-0.4, 0.4, E), rng.uniform(-spread, spread, E))
+    st.rgy[:] = np.where(near, st.rpy + rng.uniform(-0.4, 0.4, E), rng.uniform(-spread, spread, E))
+    st.rr[:] = 0.3
+    crowded = rng.uniform(size=(E, 1)) < crowded_frac
+    far = rng.uniform(-spread - 1, spread + 1, (E, N, 2))
+    ang, d = rng.uniform(0, 2 * np.pi, (E, N)), rng.uniform(0.3, 1.6, (E, N))
+    close = np.stack([st.rpx[:, None] + d * np.cos(ang), st.rpy[:, None] + d * np.sin(ang)], -1)
+    pos = np.where(crowded[..., None], close, far)
+    st.hpx[:], st.hpy[:] = pos[..., 0], pos[..., 1]
+    spd, va = rng.uniform(0, 1.2, (E, N)), rng.uniform(0, 2 * np.pi, (E, N))
+    st.hvx[:], st.hvy[:] = spd * np.cos(va), spd * np.sin(va)
+    st.hgx[:] = rng.uniform(-spread - 1, spread + 1, (E, N)); st.hgy[:] = rng.uniform(-spread - 1, spread + 1, (E, N))
+    if randomize:
+        st.hr[:] = rng.uniform(0.3, 0.5, (E, N)); st.hvpref[:] = rng.uniform(0.5, 1.5, (E, N))
+    else:
+        st.hr[:] = 0.3; st.hvpref[:] = 1.0
+    st.gtime[:] = rng.choice([0.0, 2.5, 10.25, 23.75, 24.0, 24.25], E, p=[0.4, 0.2, 0.2, 0.1, 0.05, 0.05])
+    return st
+
+
+def make_vec_env(E, N, robot_visible=False, kinematics="holonomic", cls=None, **cfg_over):
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.envs.crowd_sim import VecCrowdSim
+    from modelcrowdnav_amd.envs.utils.robot import Robot
+    from modelcrowdnav_amd.envs.policy.policy_factory import policy_factory
+    over = {"sim.human_num": N, "robot.visible": "true" if robot_visible else "false"}
+    over.update(cfg_over)
+    cfg = configs.env_config(**over)
+    env = (cls or VecCrowdSim)(E)
+    env.configure(cfg)
+    robot = Robot(cfg, "robot")
+    pol = policy_factory["orca"]()
+    pol.multiagent_training = True
+    robot.set_policy(pol)
+    robot.kinematics = kinematics
+    env.set_robot(robot)
+    return env
+
+
+def upload(env, st):
+    """oracle EnvState -> device tensors of a VecCrowdSim."""
+    import torch
+    if env._alloc_N != st.N:
+        env._allocate(st.N)
+    dev = env.device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    env.hpos.copy_(t(np.stack([st.hpx, st.hpy], -1))); env.hvel.copy_(t(np.stack([st.hvx, st.hvy], -1)))
+    env.hgoal.copy_(t(np.stack([st.hgx, st.hgy], -1))); env.hattr.copy_(t(np.stack([st.hr, st.hvpref], -1)))
+    env.rpos.copy_(t(np.stack([st.rpx, st.rpy], -1))); env.rvel.copy_(t(np.stack([st.rvx, st.rvy], -1)))
+    env.rgoal.copy_(t(np.stack([st.rgx, st.rgy], -1)))
+    env.rattr.copy_(t(np.stack([st.rr, np.ones_like(st.rr)], -1)))
+    env.gtime.copy_(t(st.gtime)); env.human_times.copy_(t(st.human_times))
+    env.human_num = st.N
+
+
+def download(env):
+    st = cport.EnvState(env.num_envs, env._alloc_N)
+    c = lambda x: x.detach().cpu().numpy()
+    hp, hv, hg, ha = c(env.hpos), c(env.hvel), c(env.hgoal), c(env.hattr)
+    st.hpx[:], st.hpy[:], st.hvx[:], st.hvy[:] = hp[..., 0], hp[..., 1], hv[..., 0], hv[..., 1]
+    st.hgx[:], st.hgy[:], st.hr[:], st.hvpref[:] = hg[..., 0], hg[..., 1], ha[..., 0], ha[..., 1]
+    rp, rv, rg, ra = c(env.rpos), c(env.rvel), c(env.rgoal), c(env.rattr)
+    st.rpx[:], st.rpy[:], st.rvx[:], st.rvy[:] = rp[:, 0], rp[:, 1], rv[:, 0], rv[:, 1]
+    st.rgx[:], st.rgy[:], st.rr[:] = rg[:, 0], rg[:, 1], ra[:, 0]
+    st.gtime[:] = c(env.gtime); st.human_times[:] = c(env.human_times)
+    return st
+
+
+STATE_FIELDS = cport.EnvState.FIELDS_H + cport.EnvState.FIELDS_R + ("gtime", "human_times")
+
+
+def assert_state_equal(a, b, fields=STATE_FIELDS, what=""):
+    for k in fields:
+        x, y = getattr(a, k), getattr(b, k)
+        if not np.array_equal(x, y):
+            bad = np.argwhere(x != y)
+            raise AssertionError("%s field %s differs at %d places, first %s: %r vs %r" % (
+                what, k, len(bad), bad[0], x[tuple(bad[0])], y[tuple(bad[0])]))
+
+
+def oracle_cfg_for(env, human_policy=cport.HUMANS_ORCA):
+    return cport.default_cfg(time_step=env.time_step, time_limit=float(env.time_limit),
+                             success_reward=env.success_reward, collision_penalty=env.collision_penalty,
+                             discomfort_dist=env.discomfort_dist,
+                             discomfort_penalty_factor=env.discomfort_penalty_factor,
+                             robot_visible=1 if env.robot.visible else 0, human_policy=human_policy,
+                             count_hh=1 if env.count_hh else 0, track_human_times=1 if env.track_human_times else 0)

@@ -1,0 +1,155 @@
+"""GPU parity of mcn_env_step (through the C ABI) against the C oracle and the reference fixtures.
+
+Bar (BASELINE.json north_star): done / info / collision masks and integer counts bit-exact,
+float state within 1e-5.  Achieved here: float state bit-exact for ORCA / given-velocity
+humans; `linear` humans use device atan2/cos/sin and are held to 1e-12.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cport  # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def _step_both(env, st, ax, ay, update, policy=cport.HUMANS_ORCA, given=None):
+    torch = _torch()
+    H.upload(env, st)
+    act = torch.from_numpy(np.stack([ax, ay], -1)).to(env.device)
+    gv = None if given is None else torch.from_numpy(np.ascontiguousarray(given)).to(env.device)
+    if policy == cport.HUMANS_LINEAR:
+        env.human_policy_name = "linear"
+    ob, reward, done, info = env.step(act, update=update, given_v=gv)
+    torch.cuda.synchronize()
+    ref_st = st.copy()
+    ref = cport.env_step(H.oracle_cfg_for(env, policy), ref_st, ax, ay, update=update, given_v=given)
+    got = dict(reward=reward.cpu().numpy(), done=done.cpu().numpy(), info=info.cpu().numpy(),
+               dmin=env.dmin.cpu().numpy(), hh_count=env.hh_count.cpu().numpy(),
+               human_act=env.human_act.cpu().numpy())
+    if not update:
+        got.update(nobs_px=ob.pos[..., 0].cpu().numpy(), nobs_py=ob.pos[..., 1].cpu().numpy(),
+                   nobs_vx=ob.vel[..., 0].cpu().numpy(), nobs_vy=ob.vel[..., 1].cpu().numpy())
+    return got, ref, ref_st
+
+
+@pytest.mark.parametrize("N,visible,randomize", [(5, False, False), (5, True, False), (10, False, True),
+                                                 (10, True, True), (1, False, False), (2, True, False),
+                                                 (7, False, True), (9, True, False), (13, False, True),
+                                                 (32, False, False)])
+@pytest.mark.parametrize("update", [True, False])
+def test_step_matches_oracle_bitexact(N, visible, randomize, update):
+    rng = np.random.RandomState(100 + N + 7 * visible)
+    E = 777   # ragged: not a multiple of the envs-per-wave count
+    env = H.make_vec_env(E, N, robot_visible=visible)
+    st = H.random_state(rng, E, N, randomize=randomize)
+    sp, aa = rng.uniform(0, 1, E), rng.uniform(0, 2 * np.pi, E)
+    got, ref, ref_st = _step_both(env, st, sp * np.cos(aa), sp * np.sin(aa), update)
+    for k in ("done", "info", "hh_count"):
+        assert np.array_equal(got[k], ref[k]), k
+    for k in [k for k in ref if k not in ("done", "info", "hh_count")]:
+        assert np.array_equal(got[k], ref[k]), k
+    if update:
+        H.assert_state_equal(H.download(env), ref_st, what="N=%d" % N)
+    else:
+        H.assert_state_equal(H.download(env), st, what="lookahead must not mutate")
+
+
+def test_given_velocity_and_linear_modes():
+    rng = np.random.RandomState(5)
+    E, N = 1000, 5
+    env = H.make_vec_env(E, N)
+    env.count_hh = False
+    st = H.random_state(rng, E, N)
+    gv = rng.uniform(-1, 1, (E, N, 2))
+    ax, ay = rng.uniform(-1, 1, E), rng.uniform(-1, 1, E)
+    got, ref, ref_st = _step_both(env, st, ax, ay, True, cport.HUMANS_GIVEN, gv)
+    for k in ref:
+        assert np.array_equal(got[k], ref[k]), k
+    H.assert_state_equal(H.download(env), ref_st)
+    env2 = H.make_vec_env(E, N)
+    got, ref, ref_st = _step_both(env2, st, ax, ay, True, cport.HUMANS_LINEAR)
+    assert np.array_equal(got["done"], ref["done"]) and np.array_equal(got["info"], ref["info"])
+    np.testing.assert_allclose(got["human_act"], ref["human_act"], rtol=0, atol=1e-12)
+    d = H.download(env2)
+    np.testing.assert_allclose(d.hpx, ref_st.hpx, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("name,policy", [("g2_step_given", cport.HUMANS_GIVEN), ("g2_step_linear", cport.HUMANS_LINEAR),
+                                         ("g2_step_orca", cport.HUMANS_ORCA),
+                                         ("g2_step_orca_visible", cport.HUMANS_ORCA)])
+def test_step_matches_reference_fixtures(name, policy, golden_dir):
+    """HIP path against values recorded from the real reference env (tools/gen_golden.py)."""
+    torch = _torch()
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    visible = bool(g["robot_visible"])
+    tol = 1e-12 if policy == cport.HUMANS_LINEAR else 0.0
+    for N in np.unique(g["N"]):
+        for update in (True, False):
+            sel = np.where((g["N"] == N) & (g["update"] == update))[0]
+            if len(sel) == 0:
+                continue
+            E, N = len(sel), int(N)
+            env = H.make_vec_env(E, N, robot_visible=visible)
+            env.count_hh = policy != cport.HUMANS_GIVEN
+            st = cport.EnvState(E, N)
+            h, r = g["hum_in"][sel][:, :N], g["rob_in"][sel]
+            st.hpx[:], st.hpy[:], st.hvx[:], st.hvy[:], st.hr[:] = h[..., 0], h[..., 1], h[..., 2], h[..., 3], h[..., 4]
+            st.hgx[:], st.hgy[:], st.hvpref[:] = h[..., 5], h[..., 6], h[..., 7]
+            st.rpx[:], st.rpy[:], st.rvx[:], st.rvy[:], st.rr[:] = r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4]
+            st.rgx[:], st.rgy[:] = r[:, 5], r[:, 6]
+            st.gtime[:] = g["time"][sel]
+            H.upload(env, st)
+            env.human_policy_name = {cport.HUMANS_LINEAR: "linear"}.get(policy, "orca")
+            act = torch.from_numpy(g["act"][sel]).to(env.device)
+            gv = torch.from_numpy(g["given_v"][sel][:, :N].copy()).to(env.device) if policy == cport.HUMANS_GIVEN else None
+            ob, reward, done, info = env.step(act, update=bool(update), given_v=gv)
+            assert np.array_equal(done.cpu().numpy(), g["done"][sel].astype(np.uint8))
+            assert np.array_equal(info.cpu().numpy(), g["info"][sel].astype(np.uint8))
+            np.testing.assert_allclose(reward.cpu().numpy(), g["reward"][sel], rtol=0, atol=tol)
+            danger = g["info"][sel] == 1
+            np.testing.assert_allclose(env.dmin.cpu().numpy()[danger], g["dmin"][sel][danger], rtol=0, atol=tol)
+            want = g["obs"][sel][:, :N]
+            np.testing.assert_allclose(ob.pos.cpu().numpy(), want[..., 0:2], rtol=0, atol=tol)
+            np.testing.assert_allclose(ob.vel.cpu().numpy(), want[..., 2:4], rtol=0, atol=tol)
+            if update:
+                ro = g["rob_out"][sel]
+                np.testing.assert_allclose(env.rpos.cpu().numpy(), ro[:, 0:2], rtol=0, atol=tol)
+                np.testing.assert_allclose(env.rvel.cpu().numpy(), ro[:, 2:4], rtol=0, atol=tol)
+                np.testing.assert_allclose(env.gtime.cpu().numpy(), g["time_out"][sel], rtol=0, atol=0)
+                if policy != cport.HUMANS_GIVEN:
+                    np.testing.assert_allclose(env.human_times.cpu().numpy(), g["human_times"][sel][:, :N], rtol=0, atol=0)
+
+
+def test_rollout_4096x5_bitexact_trajectory():
+    """BASELINE config 2 shape: 4096 envs x 5 humans, ORCA humans, random robot actions, 60 steps.
+    Whole trajectories must stay bit-identical to the oracle (any 1-ulp slip would compound)."""
+    torch = _torch()
+    from modelcrowdnav_amd.envs import scenarios as S
+    E, N, T = 4096, 5, 60
+    env = H.make_vec_env(E, N)
+    env.reset("test", test_cases=[i % 500 for i in range(E)])
+    st = H.download(env)
+    cfg = H.oracle_cfg_for(env)
+    rng = np.random.RandomState(0)
+    done_total = 0
+    for t in range(T):
+        sp, aa = rng.uniform(0, 1, E), rng.uniform(0, 2 * np.pi, E)
+        ax, ay = sp * np.cos(aa), sp * np.sin(aa)
+        ob, reward, done, info = env.step(torch.from_numpy(np.stack([ax, ay], -1)).to(env.device))
+        ref = cport.env_step(cfg, st, ax, ay, update=True)
+        assert np.array_equal(done.cpu().numpy(), ref["done"]), t
+        assert np.array_equal(info.cpu().numpy(), ref["info"]), t
+        assert np.array_equal(reward.cpu().numpy(), ref["reward"]), t
+        assert np.array_equal(env.hh_count.cpu().numpy(), ref["hh_count"]), t
+        done_total += int(ref["done"].sum())
+    H.assert_state_equal(H.download(env), st, what="after %d steps" % T)
+    assert done_total > 0

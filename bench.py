@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the batched CrowdSim rollout hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): 4096 envs x 5 humans per GPU, ORCA humans, robot actions
+drawn uniformly from the 81-entry action table by torch.Generator(seed=0), robot invisible,
+scenarios = test cases 1000 + (global_env_id mod 500), auto-reset on done from an HBM-resident
+pool of the same 500 scenarios, Explorer-style discounted returns accumulated in-kernel.
+A "step" is one mcn_env_step launch over the whole batch.  Inputs (states, the per-step action
+tensors) are resident in HBM before the timed region; the K steps are replayed from one hipGraph.
+Envs shard across ranks with no per-step communication (weak scaling); at the end of the
+rollout one RCCL all_gather collects episode returns + outcome codes.
+
+Prints ONE JSON line (rank 0).  Extra objects: roofline (dominant kernel, live HIP-event timing),
+roofline_sweep (same kernel at larger batches, where HBM rather than launch latency bounds it),
+cpu_baseline (the C oracle on this host's cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def algorithmic_bytes_per_env_step(N):
+    """(17 + 12 N) float64 scalars + 6 B of masks/counters."""
+    return (17 + 12 * N) * 8 + 6
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--humans", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--sweep", type=str, default="65536,1048576,4194304", help="extra batch sizes for roofline_sweep")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    return ap.parse_args()
+
+
+def build_env(E, N, rank_offset, device):
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.envs.crowd_sim import VecCrowdSim
+    from modelcrowdnav_amd.envs.utils.robot import Robot
+    from modelcrowdnav_amd.envs.policy.policy_factory import policy_factory
+    from modelcrowdnav_amd.envs import scenarios as S
+    cfg = configs.env_config(**{"sim.human_num": N})
+    env = VecCrowdSim(E, device)
+    env.configure(cfg)
+    robot = Robot(cfg, "robot")
+    pol = policy_factory["orca"]()          # carrier only: actions come from the random table
+    pol.multiagent_training = True
+    robot.set_policy(pol)
+    env.set_robot(robot)
+    pool = S.scenario_pool(env.spec(), "test", range(500), N, "circle_crossing")      # [500,N,9]
+    ids = (rank_offset + np.arange(E)) % 500
+    env.load_scenarios(pool[ids])
+    env.attach_rollout(gamma=0.9, pool=pool, case_stride=1, first_cases=(ids + 1) % 500)
+    return env, pool
+
+
+def action_table(v_pref=1.0):
+    """The 81 holonomic actions (cadrl.py:82-102), built by the product's own policy code."""
+    from modelcrowdnav_amd.policy.cadrl import build_action_space
+    return torch.from_numpy(build_action_space(v_pref, "holonomic", 5, 16)[0])
+
+
+def make_actions(steps, E, E_total, col0, device):
+    """[steps, E, 2] float64: uniform draws over the 81-entry table, generator seed 0; drawn for the
+    whole job and sliced per rank so the result does not depend on the partition."""
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(0)
+    idx = torch.randint(0, 81, (steps, E_total), generator=gen, dtype=torch.int64)[:, col0:col0 + E]
+    tab = action_table()
+    return tab[idx].to(device).contiguous()
+
+
+def time_kernel_events(env, acts, n, given_v=None, reps=3):
+    """Average device duration of one mcn_env_step launch: HIP events (torch.cuda.Event on the launch
+    stream, i.e. the stream handed to the C ABI) around a hipGraph of n back-to-back launches of that
+    kernel and nothing else.  Returns (mean, best) ms per launch over `reps` replays."""
+    for t in range(4):
+        env.step(acts[t % acts.shape[0]], given_v=given_v)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for t in range(n):
+            env.step(acts[t % acts.shape[0]], given_v=given_v)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    per = []
+    for _ in range(reps):
+        s.record()
+        graph.replay()
+        e.record()
+        torch.cuda.synchronize()
+        per.append(s.elapsed_time(e) / n)
+    return float(np.mean(per)), float(np.min(per))
+
+
+def roofline_entry(E, N, avg_ms, extra=None, given=False):
+    # given-velocity (ModelCrowdSim / pairwise-only) mode also reads the [E,N,2] velocity input
+    by = (algorithmic_bytes_per_env_step(N) + (16 * N if given else 0)) * E
+    ach = by / (avg_ms * 1e-3) / 1e9
+    d = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+         "kernel": "mcn::env_step_kernel", "envs_per_launch": E, "algorithmic_bytes_per_launch": by,
+         "avg_launch_us": round(avg_ms * 1e3, 3)}
+    if extra:
+        d.update(extra)
+    return d
+
+
+def cpu_baseline(N, seconds):
+    """The C oracle's env step (oracle/mcn_oracle.c), one thread, on a bounded sample of the same
+    workload: 4096 envs x 5 humans from the same scenarios, random table actions."""
+    from oracle import cport
+    from modelcrowdnav_amd.envs import scenarios as S
+    E = 4096
+    spec = S.ScenarioSpec()
+    pool = S.scenario_pool(spec, "test", range(500), N, "circle_crossing")
+    sc = pool[np.arange(E) % 500]
+    st = cport.EnvState(E, N)
+    st.hpx[:], st.hpy[:], st.hgx[:], st.hgy[:] = sc[..., 0], sc[..., 1], sc[..., 2], sc[..., 3]
+    st.hr[:], st.hvpref[:] = sc[..., 7], sc[..., 8]
+    st.rpy[:], st.rgy[:], st.rr[:] = -4.0, 4.0, 0.3
+    fresh = st.copy()
+    cfg = cport.default_cfg()
+    tab = action_table().numpy()
+    rng = np.random.RandomState(0)
+    cport.env_step(cfg, st, np.zeros(E), np.zeros(E))      # warm
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        a = tab[rng.randint(0, 81, E)]
+        out = cport.env_step(cfg, st, np.ascontiguousarray(a[:, 0]), np.ascontiguousarray(a[:, 1]))
+        d = out["done"].astype(bool)
+        if d.any():        # auto-reset like the GPU run
+            for k in cport.EnvState.FIELDS_H + cport.EnvState.FIELDS_R + ("gtime", "human_times"):
+                getattr(st, k)[d] = getattr(fresh, k)[d]
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or steps >= 20000:
+            break
+    return {"value": round(E * steps / el, 1), "unit": "env-steps/sec", "cores": 1, "kind": "port",
+            "sample": "%d envs x %d humans x %d steps (%.1f s), C oracle, 1 thread of %d host cores" % (
+                E, N, steps, el, os.cpu_count())}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    E, N, K, W = args.envs, args.humans, args.steps, args.warmup
+    E_total = E * world
+
+    env, pool = build_env(E, N, rank * E, device)
+    acts = make_actions(W + K, E, E_total, rank * E, device)
+
+    # warm-up: W eager steps (also primes the allocator before capture)
+    for t in range(W):
+        env.step(acts[t])
+    torch.cuda.synchronize()
+
+    use_graph = not args.no_graph
+    if use_graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for t in range(K):
+                env.step(acts[W + t])
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gathered = None
+    barrier()
+    t0 = time.perf_counter()
+    if use_graph:
+        graph.replay()
+    else:
+        for t in range(K):
+            env.step(acts[W + t])
+    if world > 1:
+        # the path's one exchange: episode returns + outcome codes + counts, one fused buffer
+        import torch.distributed as dist
+        rb = env.rollout_buffers
+        packed = torch.stack([rb["fin_return"], rb["fin_info"].double(), rb["fin_count"].double()], 1).float()
+        gathered = torch.empty(world * E, 3, dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(gathered, packed)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    rb = env.rollout_buffers
+    episodes = int(rb["fin_count"].sum().item())
+    mean_ret = float(rb["fin_return"][rb["fin_count"] > 0].mean().item()) if episodes else float("nan")
+
+    # dominant-kernel duration, live, HIP events on the launch stream (eager launches of the same kernel)
+    avg_ms, best_ms = time_kernel_events(env, acts[W:], min(K, 1000))
+    roof = roofline_entry(E, N, avg_ms, {"best_launch_us": round(best_ms * 1e3, 3),
+                                         "timing": "HIP events around a hipGraph of %d launches" % min(K, 1000)})
+
+    result = {
+        "metric": "env-steps/sec (whole node), 5-human CrowdSim x batched envs",
+        "value": round(E_total * K / elapsed, 1), "unit": "env-steps/sec",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 6),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "%d envs x %d humans per GPU, ORCA humans, random robot actions (81-entry table), "
+                               "auto-reset, 1 mcn_env_step launch per step" % (E, N),
+                   "envs_per_gpu": E, "humans": N, "launch": "hipGraph" if use_graph else "eager",
+                   "parallelism": "env-shard x%d, no per-step collective" % world},
+        "episodes_finished": episodes, "mean_discounted_return": round(mean_ret, 6),
+        "roofline": roof,
+    }
+
+    if rank == 0 and world == 1 and not args.no_sweep:
+        sweep = []
+        del env
+        for Es in [int(x) for x in args.sweep.split(",") if x]:
+            torch.cuda.empty_cache()
+            env_s, _ = build_env(Es, N, 0, device)
+            a_s = make_actions(8, Es, Es, 0, device)
+            for t in range(8):
+                env_s.step(a_s[t])
+            torch.cuda.synchronize()
+            a_ms, _ = time_kernel_events(env_s, a_s, 50)
+            sweep.append(roofline_entry(Es, N, a_ms, {"mode": "fused ORCA + pairwise + reward + integrate",
+                                                       "env_steps_per_sec": round(Es / (a_ms * 1e-3), 1)}))
+            gv = torch.rand(Es, N, 2, dtype=torch.float64, device=device) - 0.5
+            g_ms, _ = time_kernel_events(env_s, a_s, 50, given_v=gv)
+            sweep.append(roofline_entry(Es, N, g_ms, {"mode": "pairwise + reward + integrate (given velocities, "
+                                                              "ModelCrowdSim.step)",
+                                                       "env_steps_per_sec": round(Es / (g_ms * 1e-3), 1)}, given=True))
+            del gv
+            del env_s, a_s
+        result["roofline_sweep"] = sweep
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(N, args.cpu_seconds)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -135,7 +135,6 @@ int mcn_orca_batch(const float *self, const float *others, const int32_t *n_othe
 
 /* Library self-description (host). */
 const char *mcn_version(void);
-int mcn_device_arch(char *buf, int32_t len);   /* fills e.g. "gfx950"; needs a GPU */
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,9 @@ module raises, and every env / policy entry point above it fails with it.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- FIRST: libmcn_hip.so must bind to the HIP runtime torch already loaded,
+#                     otherwise two runtimes coexist and torch streams are meaningless to our launches
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmcn_hip.so")
 
@@ -59,7 +62,6 @@ def _load():
             "or `make -C modelcrowdnav_amd/csrc`. There is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     lib.mcn_version.restype = C.c_char_p
-    lib.mcn_device_arch.argtypes = [C.c_char_p, _i]
     lib.mcn_env_step.argtypes = [C.POINTER(EnvCfg), C.POINTER(EnvState), _vp, _vp, C.POINTER(EnvOut),
                                  C.POINTER(Rollout), _i, _i, _i, _vp]
     lib.mcn_env_step.restype = C.c_int
@@ -71,7 +73,7 @@ def _load():
 lib = _load()
 
 # every symbol include/mcn.h declares; tests/test_abi.py checks the .so exports each one
-EXPORTED = ["mcn_version", "mcn_device_arch", "mcn_env_step", "mcn_orca_batch"]
+EXPORTED = ["mcn_version", "mcn_env_step", "mcn_orca_batch"]
 
 
 def check(rc, what):
@@ -85,7 +87,6 @@ def ptr(t):
 
 
 def stream_ptr(device=None):
-    import torch
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
@@ -93,7 +94,6 @@ def version():
     return lib.mcn_version().decode()
 
 
-def device_arch():
-    buf = C.create_string_buffer(64)
-    check(lib.mcn_device_arch(buf, 64), "mcn_device_arch")
-    return buf.value.decode()
+def device_arch(device=None):
+    """gcnArchName of the device the kernels will run on (queried through torch's runtime)."""
+    return torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).gcnArchName

@@ -18,18 +18,6 @@ extern "C" {
 
 const char *mcn_version(void) { return "modelcrowdnav_amd 0.1 (gfx950)"; }
 
-int mcn_device_arch(char *buf, int32_t len)
-{
-    if (!buf || len <= 0) return MCN_EINVAL;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return MCN_ELAUNCH;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return MCN_ELAUNCH;
-    strncpy(buf, prop.gcnArchName, (size_t)len - 1);
-    buf[len - 1] = 0;
-    return MCN_OK;
-}
-
 int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *actions,
                  const double *given_v, const mcn_env_out *out, const mcn_rollout *roll,
                  int32_t E, int32_t N, int32_t update, void *stream)

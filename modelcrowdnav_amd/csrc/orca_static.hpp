@@ -1,0 +1,176 @@
+// orca_static.hpp -- register-resident ORCA solve for a compile-time candidate count.
+//
+// Same arithmetic, in the same order, as orca_device.hpp (which stays as the run-time-N
+// path and as the rare 3-D LP fallback), restructured for the wave64 VALU:
+//   * candidates, their squared distances and the resulting half-planes live in VGPRs; every
+//     array index is a compile-time constant after unrolling, so nothing goes to scratch;
+//   * neighbour ordering (ascending squared distance, stable, RVO2 insertAgentNeighbor) is a
+//     fixed insertion-sort network of predicated swaps instead of data-dependent LDS traffic;
+//   * the cut-off-circle and collision cases of the half-plane construction share one code
+//     path (they differ only in the inverse time constant), halving the divergent code;
+//   * the 3-D LP (only reached when the 2-D LP is infeasible, i.e. in dense crowds) copies
+//     the lines to private memory and reuses the generic solver.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "orca_device.hpp"
+
+namespace mcn {
+
+// 1-D LP on line NO (compile-time) against lines [0, NO), closest-point objective.
+template <int NO, int NL>
+__device__ __forceinline__ bool lp1_s(const float4 (&L)[NL], float radius, float optx, float opty, float &rx, float &ry)
+{
+    const float4 ln = L[NO];
+    const float dp = dot2(ln.x, ln.y, ln.z, ln.w);
+    const float disc = dp * dp + radius * radius - dot2(ln.x, ln.y, ln.x, ln.y);
+    if (disc < 0.0f) return false;
+    const float sq = sqrtf(disc);
+    float tl = -dp - sq;
+    float tr = -dp + sq;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < NO; ++i) {
+        const float4 li = L[i];
+        const float den = det2(ln.z, ln.w, li.z, li.w);
+        const float num = det2(li.z, li.w, ln.x - li.x, ln.y - li.y);
+        if (fabsf(den) <= kRvoEps) {
+            if (num < 0.0f) ok = false;
+        } else {
+            const float t = num / den;
+            if (den >= 0.0f) tr = fminf(tr, t);
+            else             tl = fmaxf(tl, t);
+            if (tl > tr) ok = false;
+        }
+    }
+    // a failed lane keeps computing garbage that is discarded: once ok is false it stays false,
+    // and the reference returns at the first failure without touching the result
+    if (!ok) return false;
+    float t = dot2(ln.z, ln.w, optx - ln.x, opty - ln.y);
+    if (t < tl) t = tl; else if (t > tr) t = tr;
+    rx = ln.x + t * ln.z;
+    ry = ln.y + t * ln.w;
+    return true;
+}
+
+template <int I, int NL>
+struct Lp2Step {
+    static __device__ __forceinline__ void run(const float4 (&L)[NL], int n, float radius, float optx, float opty,
+                                               float &rx, float &ry, int &fail)
+    {
+        if constexpr (I < NL) {
+            if (I < n && fail == n) {
+                const float4 li = L[I];
+                if (det2(li.z, li.w, li.x - rx, li.y - ry) > 0.0f) {
+                    float nx = rx, ny = ry;
+                    if (lp1_s<I, NL>(L, radius, optx, opty, nx, ny)) { rx = nx; ry = ny; }
+                    else fail = I;
+                }
+            }
+            Lp2Step<I + 1, NL>::run(L, n, radius, optx, opty, rx, ry, fail);
+        }
+    }
+};
+
+// NC candidates in insertion order -> new velocity.  cpv[c] = (px,py,vx,vy), crad[c] = radius.
+template <int NC>
+__device__ __forceinline__ void orca_solve_static(float4 (&cpv)[NC > 0 ? NC : 1], float (&crad)[NC > 0 ? NC : 1],
+                                                  float px, float py, float vx, float vy, float radius,
+                                                  float max_speed, float prefx, float prefy, float neighbor_dist,
+                                                  int max_neighbors, float time_horizon, float time_step,
+                                                  float &outx, float &outy)
+{
+    constexpr int NL = NC < kMaxLines ? (NC > 0 ? NC : 1) : kMaxLines;
+    const float range_sq = neighbor_dist * neighbor_dist;
+    float d[NC > 0 ? NC : 1];
+    int nin = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float ddx = px - cpv[c].x, ddy = py - cpv[c].y;
+        const float dd = dot2(ddx, ddy, ddx, ddy);
+        const bool in = dd < range_sq;
+        d[c] = in ? dd : INFINITY;
+        nin += in;
+    }
+    // stable ascending insertion-sort network (strict <, so equal keys keep insertion order)
+#pragma unroll
+    for (int i = 1; i < NC; ++i) {
+#pragma unroll
+        for (int j = i; j >= 1; --j) {
+            const bool sw = d[j] < d[j - 1];
+            const float td = sw ? d[j - 1] : d[j];       d[j - 1] = sw ? d[j] : d[j - 1];       d[j] = td;
+            const float tr = sw ? crad[j - 1] : crad[j]; crad[j - 1] = sw ? crad[j] : crad[j - 1]; crad[j] = tr;
+            const float4 a = cpv[j - 1], b = cpv[j];
+            cpv[j - 1] = make_float4(sw ? b.x : a.x, sw ? b.y : a.y, sw ? b.z : a.z, sw ? b.w : a.w);
+            cpv[j]     = make_float4(sw ? a.x : b.x, sw ? a.y : b.y, sw ? a.z : b.z, sw ? a.w : b.w);
+        }
+    }
+    int nl = nin < max_neighbors ? nin : max_neighbors;
+    if (nl > NL) nl = NL;
+
+    const float inv_th = 1.0f / time_horizon;
+    const float inv_ts = 1.0f / time_step;
+    float4 L[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        if (k < NC) {
+            const float4 o = cpv[k];
+            const float rpx = o.x - px, rpy = o.y - py;
+            const float rvx = vx - o.z, rvy = vy - o.w;
+            const float dist_sq = dot2(rpx, rpy, rpx, rpy);
+            const float cr = radius + crad[k];
+            const float cr_sq = cr * cr;
+            const bool apart = dist_sq > cr_sq;
+            const float inv = apart ? inv_th : inv_ts;          // collision case uses 1/timeStep
+            const float wx = rvx - inv * rpx, wy = rvy - inv * rpy;
+            const float wl_sq = dot2(wx, wy, wx, wy);
+            const float dp1 = dot2(wx, wy, rpx, rpy);
+            float dx, dy, ux, uy;
+            if (!apart || (dp1 < 0.0f && dp1 * dp1 > cr_sq * wl_sq)) {
+                const float wl = sqrtf(wl_sq);
+                const float iw = 1.0f / wl;
+                const float uwx = wx * iw, uwy = wy * iw;
+                dx = uwy; dy = -uwx;
+                const float s = cr * inv - wl;
+                ux = s * uwx; uy = s * uwy;
+            } else {
+                const float leg = sqrtf(dist_sq - cr_sq);
+                const float id = 1.0f / dist_sq;
+                if (det2(rpx, rpy, wx, wy) > 0.0f) {
+                    dx = (rpx * leg - rpy * cr) * id;
+                    dy = (rpx * cr + rpy * leg) * id;
+                } else {
+                    dx = -((rpx * leg + rpy * cr) * id);
+                    dy = -((-rpx * cr + rpy * leg) * id);
+                }
+                const float dp2 = dot2(rvx, rvy, dx, dy);
+                ux = dp2 * dx - rvx; uy = dp2 * dy - rvy;
+            }
+            L[k] = make_float4(vx + 0.5f * ux, vy + 0.5f * uy, dx, dy);
+        } else {
+            L[k] = make_float4(0, 0, 1, 0);
+        }
+    }
+
+    // 2-D LP: start from the preferred velocity clipped to the speed disc
+    float rx, ry;
+    if (dot2(prefx, prefy, prefx, prefy) > max_speed * max_speed) {
+        const float inv = 1.0f / sqrtf(dot2(prefx, prefy, prefx, prefy));
+        rx = max_speed * (prefx * inv); ry = max_speed * (prefy * inv);
+    } else {
+        rx = prefx; ry = prefy;
+    }
+    int fail = nl;
+    Lp2Step<0, NL>::run(L, nl, max_speed, prefx, prefy, rx, ry, fail);
+
+    if (fail < nl) {
+        // dense-crowd fallback: minimise the maximum penetration (generic solver, private memory)
+        float4 buf[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) buf[k] = L[k];
+        PrivLines PL{buf};
+        lp3(PL, nl, fail, max_speed, rx, ry);
+    }
+    outx = rx; outy = ry;
+}
+
+}  // namespace mcn

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark (GPU box): per-launch time of mcn_env_step at several batch sizes and
+human-policy modes, measured with HIP events around a hipGraph of back-to-back launches.
+    python tools/kbench.py [--humans 5] [--sizes 4096,65536,1048576] [--modes orca,given]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--humans", type=int, default=5)
+    ap.add_argument("--sizes", default="4096,65536,1048576")
+    ap.add_argument("--modes", default="orca,given")
+    ap.add_argument("--visible", action="store_true")
+    ap.add_argument("--iters", type=int, default=200)
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    N = a.humans
+    for E in [int(x) for x in a.sizes.split(",")]:
+        env, _ = bench.build_env(E, N, 0, dev)
+        env.robot.visible = a.visible
+        acts = bench.make_actions(16, E, E, 0, dev)
+        gv = torch.rand(E, N, 2, dtype=torch.float64, device=dev) - 0.5
+        for mode in a.modes.split(","):
+            g = gv if mode == "given" else None
+            for t in range(8):
+                env.step(acts[t], given_v=g)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for t in range(a.iters):
+                    env.step(acts[t % 16], given_v=g)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            best = 1e9
+            for rep in range(3):
+                s.record(); graph.replay(); e.record(); torch.cuda.synchronize()
+                best = min(best, s.elapsed_time(e) / a.iters)
+            nb = bench.algorithmic_bytes_per_env_step(N) + (16 * N if mode == "given" else 0)
+            print("N=%d E=%8d mode=%-5s  %9.2f us/launch  %8.1f M env-steps/s  %7.1f GB/s (%.1f%% of 8 TB/s)" % (
+                N, E, mode, best * 1e3, E / best / 1e3, nb * E / best / 1e6, nb * E / best / 1e6 / 80.0))
+        del env
+
+
+if __name__ == "__main__":
+    main()

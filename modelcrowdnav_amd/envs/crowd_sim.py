@@ -66,7 +66,10 @@ class VecCrowdSim(object):
         self._roll = None
         self._keep = []       # tensors referenced by the rollout struct
         self.count_hh = True
-        self.track_human_times = True
+        # first-arrival bookkeeping (crowd_sim.py:418-421) and the humans' chosen velocities are extra HBM
+        # traffic nobody on the rollout path reads: opt-in (the E = 1 CrowdSim view turns both on)
+        self.track_human_times = False
+        self.export_human_actions = False
         self.init_velocity = False     # ModelCrowdSim flavour sets True
 
     # ---------------------------------------------------------------- configuration
@@ -126,6 +129,8 @@ class VecCrowdSim(object):
                                                          self.human_times)])
         self._out = _hip.EnvOut(*[_hip.ptr(t) for t in (self.reward, self.dmin, self.done, self.info, self.hh_count,
                                                         self.human_act, self.nobs_pos, self.nobs_vel)])
+        self._out_lean = _hip.EnvOut(*[_hip.ptr(t) for t in (self.reward, self.dmin, self.done, self.info,
+                                                             self.hh_count, None, self.nobs_pos, self.nobs_vel)])
 
     def _cfg_struct(self, human_policy=None):
         hp = {"orca": _hip.HUMANS_ORCA, "linear": _hip.HUMANS_LINEAR, "given": _hip.HUMANS_GIVEN}[
@@ -215,7 +220,8 @@ class VecCrowdSim(object):
             if tuple(given_v.shape) != (E, N, 2):
                 raise ValueError("given_v must be [E,N,2]")
         cfg = self._cfg_struct(policy)
-        rc = _hip.lib.mcn_env_step(cfg, self._st, _hip.ptr(actions), _hip.ptr(given_v), self._out,
+        rc = _hip.lib.mcn_env_step(cfg, self._st, _hip.ptr(actions), _hip.ptr(given_v),
+                                   self._out if self.export_human_actions else self._out_lean,
                                    self._roll if (self._roll is not None and update) else None,
                                    E, N, 1 if update else 0, _hip.stream_ptr(self.device))
         _hip.check(rc, "mcn_env_step")
@@ -407,6 +413,7 @@ class CrowdSim(object):
         self._push_host_state()
         track = len(self.human_times) == len(self.humans)
         v.track_human_times = track
+        v.export_human_actions = True
         ob, reward, done, info = v.step(self._action_tensor(action), update=update)
         pos, vel = ob.pos[0].cpu().tolist(), ob.vel[0].cpu().tolist()
         reward, done, code = float(reward.item()), bool(done.item()), int(info.item())

@@ -46,6 +46,8 @@ def make_vec_env(E, N, robot_visible=False, kinematics="holonomic", cls=None, **
     robot.set_policy(pol)
     robot.kinematics = kinematics
     env.set_robot(robot)
+    env.track_human_times = True        # parity tests compare every optional output too
+    env.export_human_actions = True
     return env
 
 

@@ -71,6 +71,7 @@ def make_env(cls_name="CrowdSim", robot_policy="orca", humans_policy="orca", **k
     pol = policy_factory[robot_policy]()
     pol.configure(policy_config())
     if robot_policy == "sarl":
+        pol.kinematics = "holonomic"            # drivers set it from --kinematics (train_model_based_sgan.py:115)
         pol.set_device(torch.device("cpu"))
         pol.set_phase("test")
     robot.set_policy(pol)

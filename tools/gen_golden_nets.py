@@ -1,0 +1,170 @@
+"""Golden fixtures for the learned parts (run through tools/gen_golden.py):
+
+  g5_sarl     CADRL.rotate in/out, SARL ValueNetwork forward with seeded default-init weights,
+              MultiHumanRL.predict action_values + chosen action      (cadrl.py:217-252, sarl.py:28-65,
+                                                                       multi_human_rl.py:11-63)
+  g6_sgan     TrajectoryGenerator.forward on the shipped zara1_8 checkpoints of both families with
+              explicit user_noise; checkpoint tensors re-serialised as plain arrays
+                                                                      (sgan/models.py:501-553)
+  g7_episode  hand-driven reset/act/step episodes: reference CrowdSim + SARL robot
+                                                                      (explorer.py:54-125)
+"""
+import os
+
+import numpy as np
+import torch
+
+from tools import gen_golden as G
+
+OUT, REF = G.OUT, G.REF
+
+
+def _sarl_policy(seed, N=5):
+    from crowd_nav.policy.sarl import SARL
+    torch.manual_seed(seed)
+    p = SARL()
+    p.configure(G.policy_config())
+    p.set_device(torch.device("cpu"))
+    p.set_phase("test")
+    p.time_step = 0.25
+    return p
+
+
+def _state_dict_arrays(model, prefix):
+    return {prefix + k.replace(".", "__"): v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def g5_sarl():
+    from crowd_sim.envs.utils.state import FullState, ObservableState, JointState
+    rng = np.random.RandomState(5)
+    rec = {}
+    # ---- rotate ----
+    pol = _sarl_policy(0)
+    for kin in ("holonomic", "unicycle"):
+        pol.kinematics = kin
+        x = rng.uniform(-4, 4, (512, 14)).astype(np.float32)
+        x[:, 4] = rng.uniform(0.3, 0.5, 512); x[:, 13] = rng.uniform(0.3, 0.5, 512); x[:, 7] = rng.uniform(0.5, 1.5, 512)
+        y = pol.rotate(torch.from_numpy(x)).numpy()
+        rec["rotate_in_" + kin] = x; rec["rotate_out_" + kin] = y
+    pol.kinematics = "holonomic"
+    # ---- value network forward, seeded default init ----
+    for seed in (0, 1):
+        p = _sarl_policy(seed)
+        rec.update(_state_dict_arrays(p.model, "w%d__" % seed))
+        for N in (5, 10, 1):
+            x = rng.uniform(-2, 2, (64, N, 13)).astype(np.float32)
+            x[:, :, 0] = np.abs(x[:, :, 0]); x[:, :, 2] = 0
+            x[:, :, :6] = x[:, :1, :6]            # self part identical across humans, as transform() builds it
+            with torch.no_grad():
+                v = p.model(torch.from_numpy(x)).numpy()
+                att = []
+                for b in range(x.shape[0]):        # reference only keeps weights[0]; run per sample
+                    p.model(torch.from_numpy(x[b:b + 1]))
+                    att.append(p.model.attention_weights.copy())
+            rec["vn%d_in_N%d" % (seed, N)] = x
+            rec["vn%d_out_N%d" % (seed, N)] = v
+            rec["vn%d_att_N%d" % (seed, N)] = np.array(att)
+    # ---- predict: action_values + chosen action ----
+    for seed in (0, 1):
+        for N in (5, 10):
+            p = _sarl_policy(seed)
+            p.kinematics = "holonomic"
+            states, vals, acts = [], [], []
+            for s in range(48):
+                rpx, rpy = rng.uniform(-3, 3, 2)
+                near_goal = s % 6 == 5
+                gx, gy = (rpx + rng.uniform(-0.2, 0.2), rpy + rng.uniform(-0.2, 0.2)) if near_goal else rng.uniform(-4, 4, 2)
+                me = FullState(rpx, rpy, rng.uniform(-1, 1), rng.uniform(-1, 1), 0.3, gx, gy, 1.0, np.pi / 2)
+                hs = []
+                for i in range(N):
+                    if s % 3 == 0 and i < 2:
+                        a, d = rng.uniform(0, 2 * np.pi), rng.uniform(0.5, 1.3)
+                        hx, hy = rpx + d * np.cos(a), rpy + d * np.sin(a)
+                    else:
+                        hx, hy = rng.uniform(-4, 4, 2)
+                    hs.append(ObservableState(hx, hy, rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(0.3, 0.5)))
+                js = JointState(me, hs)
+                with torch.no_grad():
+                    act = p.predict(js)
+                row = [me.px, me.py, me.vx, me.vy, me.radius, me.gx, me.gy, me.v_pref, me.theta]
+                states.append((np.array(row), np.array([[h.px, h.py, h.vx, h.vy, h.radius] for h in hs])))
+                acts.append([act.vx, act.vy])
+                vals.append(np.array(p.action_values) if not p.reach_destination(js) else np.full(81, np.nan))
+            rec["pred%d_N%d_self" % (seed, N)] = np.array([s[0] for s in states])
+            rec["pred%d_N%d_humans" % (seed, N)] = np.array([s[1] for s in states])
+            rec["pred%d_N%d_values" % (seed, N)] = np.array(vals)
+            rec["pred%d_N%d_action" % (seed, N)] = np.array(acts)
+            rec["pred%d_N%d_table" % (seed, N)] = np.array([[a.vx, a.vy] for a in p.action_space])
+    np.savez_compressed(os.path.join(OUT, "g5_sarl.npz"), **rec)
+    print("g5_sarl: %d arrays" % len(rec))
+
+
+def g7_episode():
+    """Reference CrowdSim (ORCA humans through the rvo2 stand-in) + SARL robot with seeded weights, driven by
+    the loop of Explorer.run_k_episodes (explorer.py:54-70,124): per-step chosen action, reward, done, info,
+    discounted return."""
+    rec = {}
+    for seed, N in ((0, 5), (1, 5), (0, 10)):
+        torch.manual_seed(seed)
+        env, robot, pol = G.make_env("CrowdSim", robot_policy="sarl", humans_policy="orca", human_num=N)
+        rec.update(_state_dict_arrays(pol.model, "ep%d_N%d_w__" % (seed, N)))
+        for case in (0, 1, 2, 3):
+            ob = env.reset("test", case)
+            done, t = False, 0
+            A, R, D, I, S = [], [], [], [], []
+            while not done:
+                rob, hum = G.full_state_rows(env)
+                with torch.no_grad():
+                    action = robot.act(ob)
+                ob, reward, done, info = env.step(action)
+                A.append([action.vx, action.vy]); R.append(reward); D.append(done); I.append(G.info_code(info))
+                S.append(np.concatenate([rob, hum.ravel()]))
+                t += 1
+            ret = sum([pow(0.9, k * robot.time_step * robot.v_pref) * r for k, r in enumerate(R)])
+            key = "ep%d_N%d_c%d_" % (seed, N, case)
+            rec[key + "actions"] = np.array(A); rec[key + "rewards"] = np.array(R); rec[key + "done"] = np.array(D)
+            rec[key + "info"] = np.array(I); rec[key + "states"] = np.array(S); rec[key + "return"] = np.array(ret)
+            rec[key + "time"] = np.array(env.global_time)
+            print("  episode seed %d N %d case %d: %d steps, outcome %d, return %.4f" % (seed, N, case, t, I[-1], ret))
+    np.savez_compressed(os.path.join(OUT, "g7_episode.npz"), **rec)
+    print("g7_episode: %d arrays" % len(rec))
+
+
+def g6_sgan():
+    from crowd_nav.policy.world_model import get_generator
+    from sgan.utils import relative_to_abs
+    rng = np.random.RandomState(6)
+    rec = {}
+    dev = torch.device("cpu")
+    for fam in ("sgan-models", "sgan-p-models"):
+        path = os.path.join(REF, "sgan", "models", fam, "zara1_8_model.pt")
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+        gen = get_generator(ck, dev)
+        gen.decoder.seq_len = 1
+        tag = "p" if "p-models" in fam else "np"
+        for k, v in ck["g_state"].items():
+            rec["%s__w__%s" % (tag, k.replace(".", "__"))] = v.numpy().copy()
+        args = ck["args"]
+        rec[tag + "__pooling_type"] = np.array(str(args["pooling_type"]))
+        rec[tag + "__dims"] = np.array([args["embedding_dim"], args["encoder_h_dim_g"], args["decoder_h_dim_g"],
+                                        args["mlp_dim"], args["bottleneck_dim"], args["noise_dim"][0]], np.int64)
+        for scene_cfg in ((6, 5), (3, 10), (4, 1)):
+            S, N = scene_cfg
+            pos0 = rng.uniform(-4, 4, (S * N, 2))
+            vel = rng.uniform(-0.4, 0.4, (S * N, 2))
+            traj = np.stack([pos0 + vel * t + rng.normal(0, 0.02, (S * N, 2)) for t in range(8)], 0)
+            traj = np.around(traj, 4).astype(np.float32)                       # [8, S*N, 2]
+            rel = np.zeros_like(traj); rel[1:] = traj[1:] - traj[:-1]
+            sse = torch.tensor([[i * N, (i + 1) * N] for i in range(S)], dtype=torch.long)
+            noise = torch.from_numpy(rng.normal(0, 1, (S, 8)).astype(np.float32))
+            with torch.no_grad():
+                pr = gen(torch.from_numpy(traj), torch.from_numpy(rel), sse, user_noise=noise)
+                pa = relative_to_abs(pr, torch.from_numpy(traj)[-1])
+            key = "%s__S%d_N%d__" % (tag, S, N)
+            rec[key + "obs_traj"] = traj; rec[key + "obs_rel"] = rel; rec[key + "noise"] = noise.numpy()
+            rec[key + "pred_rel"] = pr.numpy(); rec[key + "pred_abs"] = pa.numpy()
+    np.savez_compressed(os.path.join(OUT, "g6_sgan.npz"), **rec)
+    print("g6_sgan: %d arrays" % len(rec))
+
+
+FAMILIES = {"g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode}

@@ -133,6 +133,53 @@ int mcn_orca_batch(const float *self, const float *others, const int32_t *n_othe
                    int32_t B, int32_t M, float neighbor_dist, int32_t max_neighbors,
                    float time_horizon, float time_step, void *stream);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * SARL attention value network: 81-action one-step look-ahead (crowd_nav/policy/sarl.py:28-65,
+ * multi_human_rl.py:11-63, cadrl.py:104-129,217-252).
+ * ---------------------------------------------------------------------------------------------- */
+
+/*
+ * mcn_sarl_pack_layer -- HOST helper: permute one nn.Linear (weight [nout][kin] row-major, bias [nout])
+ * into the MFMA operand order the kernel streams (see sarl_value.hip).  kmap[t*16 + s] is the column of
+ * `weight` that input slot s of input tile t carries, or -1 for padding; KT input tiles.
+ * wfrag_out: [ceil(nout/16)][KT][64][4] floats, bfrag_out: [ceil(nout/16)][64][4] floats (may be NULL).
+ */
+int mcn_sarl_pack_layer(const float *weight, const float *bias, int32_t nout, int32_t kin,
+                        const int32_t *kmap, int32_t KT, float *wfrag_out, float *bfrag_out);
+
+/* Device pointers to the packed fragments of one ValueNetwork (state_dict keys in comments). */
+typedef struct mcn_sarl_net {
+    const float *w_m1a, *b_m1a;   /* mlp1.0        13 -> 150 */
+    const float *w_m1b, *b_m1b;   /* mlp1.2       150 -> 100 */
+    const float *w_m2a, *b_m2a;   /* mlp2.0       100 -> 100 */
+    const float *w_m2b, *b_m2b;   /* mlp2.2       100 -> 50  */
+    const float *w_ata, *b_ata;   /* attention.0  columns   0..99  (per-human half) + bias */
+    const float *w_atg;           /* attention.0  columns 100..199 (global-state half)     */
+    const float *w_atb, *b_atb;   /* attention.2  100 -> 100 */
+    const float *w_atc, *b_atc;   /* attention.4  100 -> 1   */
+    const float *w_m3a, *b_m3a;   /* mlp3.0        56 -> 150 (input tiles: pooled x4, self x1) */
+    const float *w_m3b, *b_m3b;   /* mlp3.2       150 -> 100 */
+    const float *w_m3c, *b_m3c;   /* mlp3.4       100 -> 100 */
+    const float *w_m3d, *b_m3d;   /* mlp3.6       100 -> 1   */
+} mcn_sarl_net;
+
+/* Bytes of device workspace mcn_sarl_lookahead needs for (E, N, A). */
+int64_t mcn_sarl_workspace_bytes(int32_t E, int32_t N, int32_t A);
+
+/*
+ * mcn_sarl_lookahead -- for every env and every candidate action: propagate, reward, rotate, value
+ * network, value = reward + gamma_pow * V; then the first-max-wins argmax.
+ * Replaces the `for action in self.action_space` loop of MultiHumanRL.predict (multi_human_rl.py:35-55).
+ * actions: [A][2] device; values: [E][A] device out; best: [E] int32 out (-1 = robot already at its goal,
+ * multi_human_rl.py:22; may be NULL); best_val: [E]; attention: [E][A][N] float out or NULL.
+ * gamma_pow = pow(gamma, time_step * v_pref) computed by the caller (multi_human_rl.py:52).
+ */
+int mcn_sarl_lookahead(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int32_t A,
+                       double time_step, double gamma_pow, int32_t kinematics, void *workspace,
+                       double *values, int32_t *best, double *best_val, float *attention,
+                       int32_t E, int32_t N, void *stream);
+
 /* Library self-description (host). */
 const char *mcn_version(void);
 

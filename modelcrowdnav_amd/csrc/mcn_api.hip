@@ -9,6 +9,11 @@
 
 namespace mcn {
 int launch_env_step(const StepParams &p, hipStream_t stream);
+struct SarlParams;
+long sarl_workspace_float4s(int E, int N, int A);
+int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int A, double dt,
+                  double gamma_pow, int kinematics, void *workspace, double *values, int32_t *best, double *best_val,
+                  float *attention, int E, int N, hipStream_t stream);
 int launch_orca_batch(const float *self, const float *others, const int32_t *n_other, float *out,
                       int B, int M, float neighbor_dist, int max_neighbors, float time_horizon, float time_step,
                       hipStream_t stream);
@@ -60,6 +65,58 @@ int mcn_orca_batch(const float *self, const float *others, const int32_t *n_othe
     if (!(time_horizon > 0) || !(time_step > 0)) return MCN_EINVAL;
     return mcn::launch_orca_batch(self, others, n_other, out, B, M, neighbor_dist, max_neighbors,
                                   time_horizon, time_step, (hipStream_t)stream);
+}
+
+int mcn_sarl_pack_layer(const float *weight, const float *bias, int32_t nout, int32_t kin,
+                        const int32_t *kmap, int32_t KT, float *wfrag_out, float *bfrag_out)
+{
+    if (!weight || !kmap || !wfrag_out || nout <= 0 || kin <= 0 || KT <= 0) return MCN_EINVAL;
+    const int NT = (nout + 15) / 16;
+    for (int n = 0; n < NT; ++n)
+        for (int t = 0; t < KT; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * n + (lane & 15);
+                    const int col = kmap[t * 16 + 4 * (lane >> 4) + r];
+                    float v = 0.0f;
+                    if (row < nout && col >= 0) {
+                        if (col >= kin) return MCN_EINVAL;
+                        v = weight[(size_t)row * kin + col];
+                    }
+                    wfrag_out[(((size_t)n * KT + t) * 64 + lane) * 4 + r] = v;
+                }
+    if (bfrag_out)
+        for (int n = 0; n < NT; ++n)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * n + 4 * (lane >> 4) + r;
+                    bfrag_out[((size_t)n * 64 + lane) * 4 + r] = (bias && row < nout) ? bias[row] : 0.0f;
+                }
+    return MCN_OK;
+}
+
+int64_t mcn_sarl_workspace_bytes(int32_t E, int32_t N, int32_t A)
+{
+    if (E <= 0 || N <= 0 || A <= 0) return 0;
+    return (int64_t)mcn::sarl_workspace_float4s(E, N, A) * 16;
+}
+
+int mcn_sarl_lookahead(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int32_t A,
+                       double time_step, double gamma_pow, int32_t kinematics, void *workspace,
+                       double *values, int32_t *best, double *best_val, float *attention,
+                       int32_t E, int32_t N, void *stream)
+{
+    if (!net || !st || !actions || !workspace || !values) return MCN_EINVAL;
+    if (E <= 0 || N <= 0 || N > MCN_MAX_HUMANS || A <= 0) return MCN_EINVAL;
+    if (best && !best_val) return MCN_EINVAL;
+    if (!st->hpos || !st->hvel || !st->hattr || !st->rpos || !st->rgoal || !st->rattr) return MCN_EINVAL;
+    if (kinematics == MCN_KIN_UNICYCLE && !st->rtheta) return MCN_EINVAL;
+    const float *const *fp = reinterpret_cast<const float *const *>(net);
+    for (size_t k = 0; k < sizeof(mcn_sarl_net) / sizeof(float *); ++k)
+        if (!fp[k]) return MCN_EINVAL;
+    if (!(time_step > 0)) return MCN_EINVAL;
+    return mcn::launch_sarl_c(net, st, actions, A, time_step, gamma_pow, kinematics, workspace, values, best,
+                              best_val, attention, E, N, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,376 @@
+// sarl_value.hip -- SARL 81-action one-step look-ahead, fused, for gfx950 (MI355X).
+//
+// Replaces, per environment and candidate action (crowd_nav/policy/multi_human_rl.py:35-52):
+//   propagate (cadrl.py:104-129), compute_reward (multi_human_rl.py:65-88), the [N,14] -> [N,13]
+//   agent-centric transform (cadrl.py:217-252), ValueNetwork.forward (sarl.py:28-65: mlp1, mlp2,
+//   global-state attention, un-stabilised masked softmax, pooling, mlp3) and
+//   value = reward + gamma^(dt*v_pref) * V, followed by the strict-'>' argmax (:53-55).
+//
+// Structure.  A "pair" is one (environment, action).  One wavefront owns 16 consecutive pairs and
+// carries them through the whole network with every activation in registers:
+//
+//   v_mfma_f32_16x16x4_f32 computes D[i][j] += A[i][k] B[k][j] with lane l holding A[l&15][l>>4],
+//   B[l>>4][l&15] and D[4(l>>4)+r][l&15] in accumulator register r.  We put the PAIR on j (the lane's
+//   low 4 bits) and the FEATURE on i/k.  A layer's output tile (16 features x 16 pairs) is then
+//   already, register by register, a valid B operand of the next layer: register r of lane l holds
+//   feature 4(l>>4)+r of pair l&15, i.e. B[k=l>>4][j] of the k-step that sums features {r, 4+r, 8+r,
+//   12+r}.  So layers chain with no LDS round trip, no transposes and no barriers; only the weights
+//   move, as A operands, pre-permuted on the host into exactly that order (one coalesced 16-B load per
+//   lane feeds four MFMAs).  The N humans of a pair are processed one after the other by the same
+//   lanes, which makes the reductions over humans (global-state mean, softmax denominator, pooled
+//   feature) plain per-lane register arithmetic.
+//
+//   pass 1, per human: features -> mlp1 (13->150->100); keep mlp1 output in a per-wave workspace
+//                      (L2-resident), accumulate the mean.
+//   pass 2, per human: attention (200->100->100->1) with the global half folded into the accumulator
+//                      init, exp, mlp2 (100->100->50), pooled += e * mlp2_out.
+//   tail:              mlp3 (56->150->100->100->1), value, store.
+//
+// Arithmetic: float32 MFMA is an exact k-ordered fmaf chain (no TF32), so values match the
+// reference's float32 network to summation-order noise (~1e-6); rewards are float64 in the
+// reference's operation order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mcn.h"
+
+namespace mcn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// tiles of 16 features
+constexpr int T13 = 1, T150 = 10, T100 = 7, T50 = 4, T56 = 5 /* pooled 4 + self 1 */, T1 = 1;
+
+struct SarlFrags {
+    // weight fragments [NT][KT][64 lanes] float4 and bias fragments [NT][64] float4, see pack order in
+    // modelcrowdnav_amd/policy/sarl_pack.py
+    const float4 *w_m1a, *b_m1a;   // 13 -> 150
+    const float4 *w_m1b, *b_m1b;   // 150 -> 100
+    const float4 *w_m2a, *b_m2a;   // 100 -> 100
+    const float4 *w_m2b, *b_m2b;   // 100 -> 50
+    const float4 *w_ata, *b_ata;   // attention layer 0, local half (100 -> 100), bias = attention.0.bias
+    const float4 *w_atg;           // attention layer 0, global half (100 -> 100), no bias
+    const float4 *w_atb, *b_atb;   // 100 -> 100
+    const float4 *w_atc, *b_atc;   // 100 -> 1
+    const float4 *w_m3a, *b_m3a;   // 56 -> 150   (K tiles: pooled x4, self x1)
+    const float4 *w_m3b, *b_m3b;   // 150 -> 100
+    const float4 *w_m3c, *b_m3c;   // 100 -> 100
+    const float4 *w_m3d, *b_m3d;   // 100 -> 1
+};
+
+struct SarlParams {
+    SarlFrags f;
+    // state (same buffers as mcn_env_state)
+    const double *rpos, *rvel, *rgoal, *rattr, *rtheta;   // [E][2] / [E]
+    const double *hpos, *hvel, *hattr;                    // [E*N][2]
+    const double *actions;                                // [A][2]
+    float4 *workspace;                                    // [waves][N][T100][64] float4
+    double *values;                                       // [E*A]
+    float *attention;                                     // [E*A*N] or NULL
+    int E, N, A, kinematics;
+    double dt, gamma_pow;
+};
+
+__device__ __forceinline__ double norm2d(double x0, double x1) { return sqrt(fma(x1, x1, x0 * x0)); }
+
+// out[n] = act( bias[n] (+ init) + sum_t in[t] x W[n][t] ), two accumulators in flight per step so
+// back-to-back dependent MFMAs (40-cycle latency vs 32-cycle issue) never stall the pipe.
+template <int KT, int NT, bool RELU>
+__device__ __forceinline__ void dense(const f32x4 (&in)[KT], f32x4 (&out)[NT], const float4 *__restrict__ wf,
+                                      const float4 *__restrict__ bf, int lane)
+{
+#pragma unroll
+    for (int n = 0; n < NT; n += 2) {
+        constexpr int dummy = 0; (void)dummy;
+        const bool two = (n + 1 < NT);
+        f32x4 a0, a1 = {0, 0, 0, 0};
+        { const float4 b = bf[n * 64 + lane]; a0 = (f32x4){b.x, b.y, b.z, b.w}; }
+        if (two) { const float4 b = bf[(n + 1) * 64 + lane]; a1 = (f32x4){b.x, b.y, b.z, b.w}; }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const float4 w0 = wf[(n * KT + t) * 64 + lane];
+            float4 w1 = make_float4(0, 0, 0, 0);
+            if (two) w1 = wf[((n + 1) * KT + t) * 64 + lane];
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, in[t][0], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, in[t][0], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, in[t][1], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, in[t][1], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, in[t][2], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, in[t][2], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, in[t][3], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, in[t][3], a1, 0, 0, 0);
+        }
+        if (RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a0[r] = fmaxf(a0[r], 0.0f); a1[r] = fmaxf(a1[r], 0.0f); }
+        }
+        out[n] = a0;
+        if (two) out[n + 1] = a1;
+    }
+}
+
+// same, but accumulates onto out[] (used to fold the global-state half of attention layer 0)
+template <int KT, int NT, bool RELU>
+__device__ __forceinline__ void dense_acc(const f32x4 (&in)[KT], const f32x4 (&init)[NT], f32x4 (&out)[NT],
+                                          const float4 *__restrict__ wf, int lane)
+{
+#pragma unroll
+    for (int n = 0; n < NT; n += 2) {
+        const bool two = (n + 1 < NT);
+        f32x4 a0 = init[n], a1 = {0, 0, 0, 0};
+        if (two) a1 = init[n + 1];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const float4 w0 = wf[(n * KT + t) * 64 + lane];
+            float4 w1 = make_float4(0, 0, 0, 0);
+            if (two) w1 = wf[((n + 1) * KT + t) * 64 + lane];
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, in[t][0], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, in[t][0], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, in[t][1], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, in[t][1], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, in[t][2], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, in[t][2], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, in[t][3], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, in[t][3], a1, 0, 0, 0);
+        }
+        if (RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a0[r] = fmaxf(a0[r], 0.0f); a1[r] = fmaxf(a1[r], 0.0f); }
+        }
+        out[n] = a0;
+        if (two) out[n + 1] = a1;
+    }
+}
+
+constexpr int kSarlWaves = 4;     // wavefronts per workgroup (independent; only a dispatch granule)
+
+__global__ __launch_bounds__(kSarlWaves * 64) void sarl_value_kernel(const SarlParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long gw = (long)blockIdx.x * kSarlWaves + wave;       // global wave id
+    const int j = lane & 15, q = lane >> 4;
+    const long npairs = (long)p.E * p.A;
+    const long pair0 = gw * 16;
+    if (pair0 >= npairs) return;                                // whole wave out of range
+    long pair = pair0 + j;
+    const bool valid = pair < npairs;
+    if (!valid) pair = npairs - 1;
+    const int e = (int)(pair / p.A), a = (int)(pair - (long)e * p.A);
+    const int N = p.N;
+    const double dt = p.dt;
+
+    // ---- robot after the candidate action (cadrl.py:104-129), float64 like the reference ----
+    const double2 rp = reinterpret_cast<const double2 *>(p.rpos)[e];
+    const double2 rg = reinterpret_cast<const double2 *>(p.rgoal)[e];
+    const double2 ra = reinterpret_cast<const double2 *>(p.rattr)[e];      // radius, v_pref
+    const double2 ac = reinterpret_cast<const double2 *>(p.actions)[a];
+    double npx, npy, nvx, nvy, nth;
+    if (p.kinematics == MCN_KIN_UNICYCLE) {
+        nth = p.rtheta[e] + ac.y;
+        nvx = ac.x * cos(nth); nvy = ac.x * sin(nth);
+        npx = rp.x + nvx * dt; npy = rp.y + nvy * dt;
+    } else {
+        nth = p.rtheta ? p.rtheta[e] : 0.0;
+        nvx = ac.x; nvy = ac.y;
+        npx = rp.x + ac.x * dt; npy = rp.y + ac.y * dt;
+    }
+    // ---- self part of the rotated state (cadrl.py:223-240), float32 like torch.Tensor(...) ----
+    const float spx = (float)npx, spy = (float)npy, svx = (float)nvx, svy = (float)nvy;
+    const float srad = (float)ra.x, sgx = (float)rg.x, sgy = (float)rg.y, svpref = (float)ra.y;
+    const float gdx = sgx - spx, gdy = sgy - spy;
+    const float dg = sqrtf(gdx * gdx + gdy * gdy);
+    // cos/sin of rot = atan2(gdy, gdx) without the round trip through the angle
+    const float cr = dg > 0.0f ? gdx / dg : 1.0f;
+    const float sr = dg > 0.0f ? gdy / dg : 0.0f;
+    const float f_theta = (p.kinematics == MCN_KIN_UNICYCLE) ? ((float)nth - atan2f(gdy, gdx)) : 0.0f;
+    const float f_vx = svx * cr + svy * sr;
+    const float f_vy = svy * cr - svx * sr;
+
+    float4 *ws = p.workspace + gw * (long)N * T100 * 64;
+
+    // ---- pass 1: mlp1 per human, global-state sum, reward ----
+    f32x4 gsum[T100];
+#pragma unroll
+    for (int t = 0; t < T100; ++t) gsum[t] = (f32x4){0, 0, 0, 0};
+    double dmin = INFINITY;
+    for (int i = 0; i < N; ++i) {
+        const long ha = (long)e * N + i;
+        const double2 hp = reinterpret_cast<const double2 *>(p.hpos)[ha];
+        const double2 hv = reinterpret_cast<const double2 *>(p.hvel)[ha];
+        const double hr = p.hattr[2 * ha];
+        const double qx = hp.x + hv.x * dt, qy = hp.y + hv.y * dt;      // constant-velocity propagate
+        const double d = norm2d(npx - qx, npy - qy) - ra.x - hr;        // multi_human_rl.py:70
+        dmin = fmin(dmin, d);
+        const float hx = (float)qx, hy = (float)qy, hvx = (float)hv.x, hvy = (float)hv.y, hrad = (float)hr;
+        const float ox = hx - spx, oy = hy - spy;
+        float feat[16];
+        feat[0] = dg; feat[1] = svpref; feat[2] = f_theta; feat[3] = srad; feat[4] = f_vx; feat[5] = f_vy;
+        feat[6] = ox * cr + oy * sr;
+        feat[7] = oy * cr - ox * sr;
+        feat[8] = hvx * cr + hvy * sr;
+        feat[9] = hvy * cr - hvx * sr;
+        feat[10] = hrad;
+        { const float ax_ = spx - hx, ay_ = spy - hy; feat[11] = sqrtf(ax_ * ax_ + ay_ * ay_); }
+        feat[12] = srad + hrad;
+        feat[13] = feat[14] = feat[15] = 0.0f;
+        f32x4 x[T13];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)      // register r of lane group q carries feature 4q + r
+            x[0][r] = q == 0 ? feat[r] : (q == 1 ? feat[4 + r] : (q == 2 ? feat[8 + r] : feat[12 + r]));
+        f32x4 h1[T150];
+        dense<T13, T150, true>(x, h1, p.f.w_m1a, p.f.b_m1a, lane);
+        f32x4 h2[T100];
+        dense<T150, T100, true>(h1, h2, p.f.w_m1b, p.f.b_m1b, lane);
+#pragma unroll
+        for (int t = 0; t < T100; ++t) {
+            ws[(i * T100 + t) * 64 + lane] = make_float4(h2[t][0], h2[t][1], h2[t][2], h2[t][3]);
+            gsum[t] += h2[t];
+        }
+    }
+    // reward ladder of MultiHumanRL.compute_reward with its hard-coded constants
+    const bool reach = norm2d(npx - rg.x, npy - rg.y) < ra.x;
+    double reward;
+    if (dmin < 0) reward = -0.25;
+    else if (reach) reward = 1;
+    else if (dmin < 0.2) reward = (dmin - 0.2) * 0.5 * dt;
+    else reward = 0;
+
+    // global state = mean over humans (sarl.py:41); its contribution to attention layer 0 is the same for
+    // every human of the pair, so it becomes the accumulator init of that layer
+    const float fn = (float)N;
+#pragma unroll
+    for (int t = 0; t < T100; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gsum[t][r] = gsum[t][r] / fn;
+    f32x4 gat[T100];
+    dense<T100, T100, false>(gsum, gat, p.f.w_atg, p.f.b_ata, lane);
+
+    // ---- pass 2: attention score, mlp2, pooling ----
+    f32x4 pooled[T50];
+#pragma unroll
+    for (int t = 0; t < T50; ++t) pooled[t] = (f32x4){0, 0, 0, 0};
+    float denom = 0.0f;
+    for (int i = 0; i < N; ++i) {
+        f32x4 h2[T100];
+#pragma unroll
+        for (int t = 0; t < T100; ++t) {
+            const float4 v = ws[(i * T100 + t) * 64 + lane];
+            h2[t] = (f32x4){v.x, v.y, v.z, v.w};
+        }
+        f32x4 a1[T100];
+        dense_acc<T100, T100, true>(h2, gat, a1, p.f.w_ata, lane);
+        f32x4 a2[T100];
+        dense<T100, T100, true>(a1, a2, p.f.w_atb, p.f.b_atb, lane);
+        f32x4 sc[T1];
+        dense<T100, T1, false>(a2, sc, p.f.w_atc, p.f.b_atc, lane);
+        // score of pair j sits in lane j (q = 0), register 0; broadcast to the pair's four lanes
+        const float s = __shfl(sc[0][0], j);
+        const float es = (s != 0.0f) ? expf(s) : 0.0f;          // exp(s) * (s != 0), sarl.py:52
+        if (p.attention && valid && q == 0) p.attention[pair * N + i] = es;   // normalised by the host view
+        denom += es;
+        f32x4 m1[T100];
+        dense<T100, T100, true>(h2, m1, p.f.w_m2a, p.f.b_m2a, lane);
+        f32x4 m2[T50];
+        dense<T100, T50, false>(m1, m2, p.f.w_m2b, p.f.b_m2b, lane);
+#pragma unroll
+        for (int t = 0; t < T50; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pooled[t][r] += es * m2[t][r];
+    }
+
+    // ---- tail: mlp3 on [self(6), pooled(50)] ----
+    f32x4 jin[T56];
+#pragma unroll
+    for (int t = 0; t < T50; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) jin[t][r] = pooled[t][r] / denom;
+    {
+        const float self6[8] = {dg, svpref, f_theta, srad, f_vx, f_vy, 0.0f, 0.0f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) jin[T50][r] = q == 0 ? self6[r] : (q == 1 ? self6[4 + r] : 0.0f);
+    }
+    f32x4 v1[T150];
+    dense<T56, T150, true>(jin, v1, p.f.w_m3a, p.f.b_m3a, lane);
+    f32x4 v2[T100];
+    dense<T150, T100, true>(v1, v2, p.f.w_m3b, p.f.b_m3b, lane);
+    f32x4 v3[T100];
+    dense<T100, T100, true>(v2, v3, p.f.w_m3c, p.f.b_m3c, lane);
+    f32x4 vo[T1];
+    dense<T100, T1, false>(v3, vo, p.f.w_m3d, p.f.b_m3d, lane);
+    if (valid && q == 0) {
+        // value = reward + gamma^(dt * v_pref) * V   (multi_human_rl.py:52, Python float arithmetic)
+        p.values[pair] = reward + p.gamma_pow * (double)vo[0][0];
+    }
+    if (p.attention && valid && q == 0) {
+        for (int i = 0; i < N; ++i) p.attention[pair * N + i] /= denom;
+    }
+}
+
+// Strict-'>' argmax over the A candidate values of each env (multi_human_rl.py:53-55: the first maximum
+// wins), one wavefront per env.  Also reports reach_destination (policy.py:43-49), for which the reference
+// returns the zero action without evaluating anything.
+__global__ __launch_bounds__(64) void sarl_argmax_kernel(const double *__restrict__ values, const double *rpos,
+                                                       const double *rgoal, const double *rattr, int E, int A,
+                                                       int32_t *__restrict__ best, double *__restrict__ best_val)
+{
+    const int e = blockIdx.x;
+    const int lane = threadIdx.x;
+    double bv = -INFINITY; int bi = -1;
+    for (int k = lane; k < A; k += 64) {
+        const double v = values[(long)e * A + k];
+        if (v > bv) { bv = v; bi = k; }
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const int oi = __shfl_xor(bi, off);
+        const bool take = (oi >= 0) && (bi < 0 || ov > bv || (ov == bv && oi < bi));
+        if (take) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        const double2 rp = reinterpret_cast<const double2 *>(rpos)[e];
+        const double2 rg = reinterpret_cast<const double2 *>(rgoal)[e];
+        // numpy norm((py - gy, px - gx)): dot = fma(x1, x1, x0 * x0) with x0 = py-gy, x1 = px-gx
+        const bool reached = norm2d(rp.y - rg.y, rp.x - rg.x) < rattr[2 * e];
+        best[e] = reached ? -1 : bi;
+        best_val[e] = bv;
+    }
+}
+
+int launch_sarl(const SarlParams &p, int32_t *best, double *best_val, hipStream_t stream)
+{
+    const long npairs = (long)p.E * p.A;
+    const long waves = (npairs + 15) / 16;
+    const int blocks = (int)((waves + kSarlWaves - 1) / kSarlWaves);
+    hipLaunchKernelGGL(sarl_value_kernel, dim3(blocks), dim3(kSarlWaves * 64), 0, stream, p);
+    if (best) {
+        hipLaunchKernelGGL(sarl_argmax_kernel, dim3(p.E), dim3(64), 0, stream, p.values, p.rpos, p.rgoal, p.rattr,
+                           p.E, p.A, best, best_val);
+    }
+    return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
+}
+
+int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int A, double dt,
+                  double gamma_pow, int kinematics, void *workspace, double *values, int32_t *best, double *best_val,
+                  float *attention, int E, int N, hipStream_t stream)
+{
+    SarlParams p;
+    const float4 *const *src = reinterpret_cast<const float4 *const *>(net);
+    const float4 **dst = reinterpret_cast<const float4 **>(&p.f);
+    static_assert(sizeof(SarlFrags) == sizeof(mcn_sarl_net), "fragment tables must mirror the C struct");
+    for (size_t k = 0; k < sizeof(mcn_sarl_net) / sizeof(float *); ++k) dst[k] = src[k];
+    p.rpos = st->rpos; p.rvel = st->rvel; p.rgoal = st->rgoal; p.rattr = st->rattr; p.rtheta = st->rtheta;
+    p.hpos = st->hpos; p.hvel = st->hvel; p.hattr = st->hattr;
+    p.actions = actions; p.workspace = reinterpret_cast<float4 *>(workspace);
+    p.values = values; p.attention = attention;
+    p.E = E; p.N = N; p.A = A; p.kinematics = kinematics; p.dt = dt; p.gamma_pow = gamma_pow;
+    return launch_sarl(p, best, best_val, stream);
+}
+
+long sarl_workspace_float4s(int E, int N, int A)
+{
+    const long waves = ((long)E * A + 15) / 16;
+    const long wpad = (waves + kSarlWaves - 1) / kSarlWaves * kSarlWaves;
+    return wpad * (long)N * T100 * 64;
+}
+
+}  // namespace mcn

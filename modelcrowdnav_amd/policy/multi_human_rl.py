@@ -1,0 +1,141 @@
+"""One-step look-ahead over the action table for pairwise-state value networks
+(reference: crowd_nav/policy/multi_human_rl.py:7-104).
+
+`predict(JointState)` keeps the reference's contract -- including the draw from numpy's global
+stream before the epsilon test, the reach-destination short cut, `action_values`, `last_state`
+and the ValueError on an all-NaN network -- but the 81-iteration Python loop (propagate,
+compute_reward, 5 tiny tensors, rotate, forward, .item()) is ONE mcn_sarl_lookahead launch.
+`predict_batch(env)` is the same launch over all E environments of a VecCrowdSim, reading the
+env's HBM-resident state in place.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _hip
+from .cadrl import CADRL
+from ..envs.utils.action import ActionRot, ActionXY
+
+
+class MultiHumanRL(CADRL):
+    def __init__(self):
+        super().__init__()
+        self._frags = None        # packed MFMA operand fragments (device) + the version they were packed at
+        self._ws = None
+        self._bufs = {}
+
+    # ------------------------------------------------------------------ device plumbing
+    def _gpu_device(self):
+        d = self.device if isinstance(self.device, torch.device) else torch.device(self.device or "cuda")
+        if d.type != "cuda":
+            # the reference accepts --device cpu; this build's look-ahead only exists as HIP kernels
+            d = torch.device("cuda", torch.cuda.current_device())
+        return d
+
+    def _packed(self, dev):
+        raise NotImplementedError
+
+    def _lookahead(self, st, E, N, dev, want_attention=False):
+        """Launch mcn_sarl_lookahead on an EnvState struct; returns (values[E,A], best[E], best_val[E], att)."""
+        if self.action_space is None:
+            raise RuntimeError("action space not built")
+        A = len(self.action_space)
+        key = (E, N, A, dev)
+        if self._bufs.get("key") != key:
+            nbytes = _hip.lib.mcn_sarl_workspace_bytes(E, N, A)
+            self._bufs = {
+                "key": key,
+                "ws": torch.empty(nbytes // 4, dtype=torch.float32, device=dev),
+                "values": torch.empty(E, A, dtype=torch.float64, device=dev),
+                "best": torch.empty(E, dtype=torch.int32, device=dev),
+                "best_val": torch.empty(E, dtype=torch.float64, device=dev),
+                "table": torch.from_numpy(np.ascontiguousarray(self._action_table)).to(dev),
+                "att": None,
+            }
+        b = self._bufs
+        if want_attention and b["att"] is None:
+            b["att"] = torch.empty(E, A, N, dtype=torch.float32, device=dev)
+        net = self._packed(dev)
+        kin = _hip.KIN_UNICYCLE if self.kinematics == "unicycle" else _hip.KIN_HOLONOMIC
+        gamma_pow = pow(self.gamma, self.time_step * self._v_pref)       # multi_human_rl.py:52
+        rc = _hip.lib.mcn_sarl_lookahead(C.byref(net), st, _hip.ptr(b["table"]), A, float(self.time_step), gamma_pow, kin,
+                                         _hip.ptr(b["ws"]), _hip.ptr(b["values"]), _hip.ptr(b["best"]),
+                                         _hip.ptr(b["best_val"]), _hip.ptr(b["att"]) if want_attention else None,
+                                         E, N, _hip.stream_ptr(dev))
+        _hip.check(rc, "mcn_sarl_lookahead")
+        return b["values"], b["best"], b["best_val"], b["att"]
+
+    # ------------------------------------------------------------------ reference surface (E = 1)
+    def predict(self, state):
+        if self.phase is None or self.device is None:
+            raise AttributeError("Phase, device attributes have to be set!")
+        if self.phase == "train" and self.epsilon is None:
+            raise AttributeError("Epsilon attribute has to be set in training phase")
+        zero = ActionXY(0, 0) if self.kinematics == "holonomic" else ActionRot(0, 0)
+        if self.reach_destination(state):
+            return zero
+        me, humans = state.self_state, state.human_states
+        if self.action_space is None:
+            self.build_action_space(me.v_pref)
+        if self.with_om:
+            raise NotImplementedError("occupancy maps (with_om) are outside this build's scope")
+        if self.query_env:
+            raise NotImplementedError("query_env=true (81 full env steps per decision) is not built; "
+                                      "the shipped policy.config uses query_env=false")
+        probability = np.random.random()                       # drawn unconditionally, as the reference does
+        if self.phase == "train" and probability < self.epsilon:
+            max_action = self.action_space[np.random.choice(len(self.action_space))]
+        else:
+            dev = self._gpu_device()
+            N = len(humans)
+            f64 = torch.float64
+            t = lambda rows: torch.tensor(rows, dtype=f64, device=dev)
+            bufs = dict(hpos=t([[h.px, h.py] for h in humans]), hvel=t([[h.vx, h.vy] for h in humans]),
+                        hattr=t([[h.radius, 0.0] for h in humans]), rpos=t([[me.px, me.py]]),
+                        rvel=t([[me.vx, me.vy]]), rgoal=t([[me.gx, me.gy]]), rattr=t([[me.radius, me.v_pref]]),
+                        rtheta=t([me.theta]))
+            st = _hip.EnvState()
+            for k, v in bufs.items():
+                setattr(st, k, _hip.ptr(v))
+            self._v_pref = me.v_pref
+            values, best, _, att = self._lookahead(st, 1, N, dev, want_attention=True)
+            vals = values[0].cpu().numpy()
+            self.action_values = vals.tolist()
+            idx = int(best.item())
+            self._last_attention = att[0, max(idx, 0)].cpu().numpy()
+            if idx < 0 or not np.isfinite(vals[idx]):
+                # every value NaN <=> `value > max_value` never fired in the reference loop
+                raise ValueError("Value network is not well trained. ")
+            max_action = self.action_space[idx]
+        if self.phase == "train":
+            self.last_state = self.transform(state)
+        return max_action
+
+    def transform(self, state):
+        """multi_human_rl.py:90-104: [N,13] rotated rows (float32) for the replay memory."""
+        rows = torch.cat([torch.Tensor([state.self_state + h]).to(self.device) for h in state.human_states], dim=0)
+        if self.with_om:
+            raise NotImplementedError("occupancy maps (with_om) are outside this build's scope")
+        return self.rotate(rows)
+
+    def input_dim(self):
+        return self.joint_state_dim + (self.cell_num ** 2 * self.om_channel_size if self.with_om else 0)
+
+    # ------------------------------------------------------------------ batched surface
+    def predict_batch(self, env, want_values=False):
+        """Greedy look-ahead for all E environments of a VecCrowdSim (phase 'test'/'val').
+
+        Returns (actions [E,2] float64 device tensor, best [E] int32; -1 where the robot already
+        stands on its goal and the zero action is returned, multi_human_rl.py:22-23)."""
+        if self.action_space is None:
+            self.build_action_space(float(env.robot.v_pref))
+        dev = env.device
+        self._v_pref = float(env.robot.v_pref)
+        values, best, best_val, _ = self._lookahead(env._st, env.num_envs, env._alloc_N, dev)
+        table = self._bufs["table"]
+        idx = best.clamp(min=0).long()
+        actions = table[idx] * (best >= 0).unsqueeze(1).to(table.dtype)
+        if want_values:
+            return actions, best, values
+        return actions, best

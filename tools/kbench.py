@@ -22,7 +22,12 @@ def main():
     ap.add_argument("--modes", default="orca,given")
     ap.add_argument("--visible", action="store_true")
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--sarl", action="store_true")
     a = ap.parse_args()
+    if a.sarl:
+        for N in [int(x) for x in str(a.humans).split(",")]:
+            sarl_bench(4096, N)
+        return
     dev = torch.device("cuda", 0)
     N = a.humans
     for E in [int(x) for x in a.sizes.split(",")]:
@@ -48,6 +53,39 @@ def main():
             print("N=%d E=%8d mode=%-5s  %9.2f us/launch  %8.1f M env-steps/s  %7.1f GB/s (%.1f%% of 8 TB/s)" % (
                 N, E, mode, best * 1e3, E / best / 1e3, nb * E / best / 1e6, nb * E / best / 1e6 / 80.0))
         del env
+
+
+
+
+def sarl_bench(E=4096, N=5, iters=5):
+    """mcn_sarl_lookahead alone and SARL-driven env steps (BASELINE config 3)."""
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.policy.sarl import SARL
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    pol = SARL(); pol.configure(configs.policy_config()); pol.kinematics = "holonomic"
+    pol.set_device(dev); pol.set_phase("test"); pol.time_step = 0.25
+    env, _ = bench.build_env(E, N, 0, dev)
+    for _ in range(2):
+        a, b = pol.predict_batch(env)
+        env.step(a)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        pol.predict_batch(env)
+    e.record(); torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    flop = 81 * (N * 124100 + 67000) * E
+    print("SARL lookahead N=%d E=%d: %.3f ms/launch  %.1f TFLOP/s algorithmic (fp32 MFMA peak 157.3)  %.3f M env-steps/s" % (
+        N, E, ms, flop / ms / 1e9, E / ms / 1e3))
+    s.record()
+    for _ in range(iters):
+        a, b = pol.predict_batch(env)
+        env.step(a)
+    e.record(); torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    print("SARL-driven env step N=%d E=%d: %.3f ms/step  %.3f M env-steps/s" % (N, E, ms, E / ms / 1e3))
 
 
 if __name__ == "__main__":

@@ -140,12 +140,12 @@ int mcn_orca_batch(const float *self, const float *others, const int32_t *n_othe
  * ---------------------------------------------------------------------------------------------- */
 
 /*
- * mcn_sarl_pack_layer -- HOST helper: permute one nn.Linear (weight [nout][kin] row-major, bias [nout])
- * into the MFMA operand order the kernel streams (see sarl_value.hip).  kmap[t*16 + s] is the column of
+ * mcn_pack_linear -- HOST helper: permute one nn.Linear (weight [nout][kin] row-major, bias [nout])
+ * into the MFMA operand order the network kernels stream (see mfma_chain.hpp; used for SARL and SGAN).  kmap[t*16 + s] is the column of
  * `weight` that input slot s of input tile t carries, or -1 for padding; KT input tiles.
  * wfrag_out: [ceil(nout/16)][KT][64][4] floats, bfrag_out: [ceil(nout/16)][64][4] floats (may be NULL).
  */
-int mcn_sarl_pack_layer(const float *weight, const float *bias, int32_t nout, int32_t kin,
+int mcn_pack_linear(const float *weight, const float *bias, int32_t nout, int32_t kin,
                         const int32_t *kmap, int32_t KT, float *wfrag_out, float *bfrag_out);
 
 /* Device pointers to the packed fragments of one ValueNetwork (state_dict keys in comments). */
@@ -179,6 +179,40 @@ int mcn_sarl_lookahead(const mcn_sarl_net *net, const mcn_env_state *st, const d
                        double time_step, double gamma_pow, int32_t kinematics, void *workspace,
                        double *values, int32_t *best, double *best_val, float *attention,
                        int32_t E, int32_t N, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Social-GAN one-step world model (crowd_nav/policy/world_model.py:134-268, sgan/models.py:501-553).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Device pointers to packed fragments of one TrajectoryGenerator (shipped architecture: embedding 16,
+ * encoder/decoder hidden 32, mlp 64, bottleneck 8, noise 8 'global', pool hidden 512, no batch norm). */
+typedef struct mcn_sgan_net {
+    const float *w_eemb, *b_eemb;     /* encoder.spatial_embedding */
+    const float *w_elstm, *b_elstm;   /* encoder.encoder [weight_ih_l0 | weight_hh_l0], bias_ih_l0 + bias_hh_l0 */
+    const float *w_pemb, *b_pemb;     /* pool_net.spatial_embedding      (pooling models only) */
+    const float *w_p1, *b_p1;         /* pool_net.mlp_pre_pool.0 */
+    const float *w_p2, *b_p2;         /* pool_net.mlp_pre_pool.2 */
+    const float *w_c1, *b_c1;         /* mlp_decoder_context.0 */
+    const float *w_c2, *b_c2;         /* mlp_decoder_context.2 */
+    const float *w_demb, *b_demb;     /* decoder.spatial_embedding */
+    const float *w_dlstm, *b_dlstm;   /* decoder.decoder [weight_ih_l0 | weight_hh_l0], bias sum */
+    const float *w_h2p, *b_h2p;       /* decoder.hidden2pos */
+    int32_t pooling;                  /* 1: pooling_type == 'pool_net', 0: none */
+} mcn_sgan_net;
+
+int64_t mcn_sgan_workspace_bytes(int32_t E, int32_t N);
+
+/*
+ * mcn_sgan_step -- one SGANWorld.forward for E scenes of N pedestrians.
+ * hist: [E][8][N][2] float64 ring of positions already rounded to 1e-4.  If cur_pos ([E*N][2]) is not NULL it
+ * is rounded and written to ring slot `push_slot` first (the frame the reference appends to its cache file,
+ * world_model.py:238-240).  `oldest` is the ring slot of the oldest of the 8 frames AFTER that push.
+ * noise: [E][8] float (user_noise, sgan/models.py:475); out_vel: [E*N][2] float64 velocities
+ * (world_model.py:266-268); out_rel: [E*N][2] float predicted displacement or NULL.
+ */
+int mcn_sgan_step(const mcn_sgan_net *net, double *hist, int32_t push_slot, int32_t oldest, const double *cur_pos,
+                  const float *noise, void *workspace, double *out_vel, float *out_rel, double time_step,
+                  int32_t E, int32_t N, void *stream);
 
 /* Library self-description (host). */
 const char *mcn_version(void);

@@ -68,21 +68,25 @@ def _load():
     lib.mcn_orca_batch.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _f, _f, _vp]
     lib.mcn_orca_batch.restype = C.c_int
     fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
-    lib.mcn_sarl_pack_layer.argtypes = [fp, fp, _i, _i, ip, _i, fp, fp]
-    lib.mcn_sarl_pack_layer.restype = C.c_int
+    lib.mcn_pack_linear.argtypes = [fp, fp, _i, _i, ip, _i, fp, fp]
+    lib.mcn_pack_linear.restype = C.c_int
     lib.mcn_sarl_workspace_bytes.argtypes = [_i, _i, _i]
     lib.mcn_sarl_workspace_bytes.restype = C.c_int64
     lib.mcn_sarl_lookahead.argtypes = [_vp, C.POINTER(EnvState), _vp, _i, _d, _d, _i, _vp, _vp, _vp, _vp, _vp,
                                        _i, _i, _vp]
     lib.mcn_sarl_lookahead.restype = C.c_int
+    lib.mcn_sgan_workspace_bytes.argtypes = [_i, _i]
+    lib.mcn_sgan_workspace_bytes.restype = C.c_int64
+    lib.mcn_sgan_step.argtypes = [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _vp]
+    lib.mcn_sgan_step.restype = C.c_int
     return lib
 
 
 lib = _load()
 
 # every symbol include/mcn.h declares; tests/test_abi.py checks the .so exports each one
-EXPORTED = ["mcn_version", "mcn_env_step", "mcn_orca_batch", "mcn_sarl_pack_layer", "mcn_sarl_workspace_bytes",
-            "mcn_sarl_lookahead"]
+EXPORTED = ["mcn_version", "mcn_env_step", "mcn_orca_batch", "mcn_pack_linear", "mcn_sarl_workspace_bytes",
+            "mcn_sarl_lookahead", "mcn_sgan_workspace_bytes", "mcn_sgan_step"]
 
 
 def check(rc, what):

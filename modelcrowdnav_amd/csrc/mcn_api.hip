@@ -14,6 +14,9 @@ long sarl_workspace_float4s(int E, int N, int A);
 int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int A, double dt,
                   double gamma_pow, int kinematics, void *workspace, double *values, int32_t *best, double *best_val,
                   float *attention, int E, int N, hipStream_t stream);
+int launch_sgan(const mcn_sgan_net *net, double *hist, int push_slot, int oldest, const double *cur_pos,
+                const float *noise, void *workspace, double *out_vel, float *out_rel, double time_step, int E, int N,
+                hipStream_t stream);
 int launch_orca_batch(const float *self, const float *others, const int32_t *n_other, float *out,
                       int B, int M, float neighbor_dist, int max_neighbors, float time_horizon, float time_step,
                       hipStream_t stream);
@@ -67,7 +70,7 @@ int mcn_orca_batch(const float *self, const float *others, const int32_t *n_othe
                                   time_horizon, time_step, (hipStream_t)stream);
 }
 
-int mcn_sarl_pack_layer(const float *weight, const float *bias, int32_t nout, int32_t kin,
+int mcn_pack_linear(const float *weight, const float *bias, int32_t nout, int32_t kin,
                         const int32_t *kmap, int32_t KT, float *wfrag_out, float *bfrag_out)
 {
     if (!weight || !kmap || !wfrag_out || nout <= 0 || kin <= 0 || KT <= 0) return MCN_EINVAL;
@@ -117,6 +120,28 @@ int mcn_sarl_lookahead(const mcn_sarl_net *net, const mcn_env_state *st, const d
     if (!(time_step > 0)) return MCN_EINVAL;
     return mcn::launch_sarl_c(net, st, actions, A, time_step, gamma_pow, kinematics, workspace, values, best,
                               best_val, attention, E, N, (hipStream_t)stream);
+}
+
+int64_t mcn_sgan_workspace_bytes(int32_t E, int32_t N)
+{
+    if (E <= 0 || N <= 0) return 0;
+    return (int64_t)E * N * (32 + 4) * 4;
+}
+
+int mcn_sgan_step(const mcn_sgan_net *net, double *hist, int32_t push_slot, int32_t oldest, const double *cur_pos,
+                  const float *noise, void *workspace, double *out_vel, float *out_rel, double time_step,
+                  int32_t E, int32_t N, void *stream)
+{
+    if (!net || !hist || !noise || !workspace || !out_vel) return MCN_EINVAL;
+    if (E <= 0 || N <= 0 || N > MCN_MAX_HUMANS) return MCN_EINVAL;
+    if (push_slot < 0 || push_slot > 7 || oldest < 0 || oldest > 7 || !(time_step > 0)) return MCN_EINVAL;
+    const float *const *fp = reinterpret_cast<const float *const *>(net);
+    for (int k = 0; k < 20; ++k) {
+        const bool pool_only = (k >= 4 && k < 10);
+        if (!fp[k] && !(pool_only && !net->pooling)) return MCN_EINVAL;
+    }
+    return mcn::launch_sgan(net, hist, push_slot, oldest, cur_pos, noise, workspace, out_vel, out_rel, time_step,
+                            E, N, (hipStream_t)stream);
 }
 
 }  // extern "C"

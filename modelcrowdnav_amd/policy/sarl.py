@@ -50,7 +50,7 @@ class ValueNetwork(nn.Module):
         return self.mlp3(torch.cat([state[:, 0, :self.self_state_dim], pooled], dim=1))
 
 
-# input-slot -> weight-column maps of each packed layer (see mcn_sarl_pack_layer in include/mcn.h)
+# input-slot -> weight-column maps of each packed layer (see mcn_pack_linear in include/mcn.h)
 def _ident(kin, tiles, offset=0):
     m = np.full(tiles * 16, -1, np.int32)
     m[:kin] = np.arange(kin) + offset
@@ -100,10 +100,10 @@ def pack_value_network(model, dev):
         NT = (nout + 15) // 16
         wf = np.zeros((NT, KT, 64, 4), np.float32)
         bf = np.zeros((NT, 64, 4), np.float32)
-        rc = _hip.lib.mcn_sarl_pack_layer(W.ctypes.data_as(fp), b.ctypes.data_as(fp), nout, kin,
+        rc = _hip.lib.mcn_pack_linear(W.ctypes.data_as(fp), b.ctypes.data_as(fp), nout, kin,
                                           kmap.ctypes.data_as(C.POINTER(C.c_int32)), KT, wf.ctypes.data_as(fp),
                                           bf.ctypes.data_as(fp) if with_bias else None)
-        _hip.check(rc, "mcn_sarl_pack_layer(%s)" % name)
+        _hip.check(rc, "mcn_pack_linear(%s)" % name)
         dw = torch.from_numpy(wf).to(dev)
         keep.append(dw)
         setattr(net, "w_" + name, dw.data_ptr())

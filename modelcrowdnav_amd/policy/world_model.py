@@ -1,0 +1,155 @@
+"""World models that advance the humans inside ModelCrowdSim (reference: crowd_nav/policy/world_model.py).
+
+  get_generator   :108-131  build a TrajectoryGenerator from a checkpoint dict
+  SGANWorld       :134-268  E = 1 callable with the reference's constructor and return type
+  VecSGANWorld              the same step for E scenes, history kept as a ring in HBM
+
+MlpWorld / AttentionWorld (:22-106) are the next tier and not built.
+"""
+import logging
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+from ..sgan.models import TrajectoryGenerator, sgan_step
+
+
+def get_generator(checkpoint, device):
+    a = checkpoint["args"]
+    get = a.get if isinstance(a, dict) else (lambda k: getattr(a, k))
+    gen = TrajectoryGenerator(
+        obs_len=get("obs_len"), pred_len=get("pred_len"), embedding_dim=get("embedding_dim"),
+        encoder_h_dim=get("encoder_h_dim_g"), decoder_h_dim=get("decoder_h_dim_g"), mlp_dim=get("mlp_dim"),
+        num_layers=get("num_layers"), noise_dim=get("noise_dim"), noise_type=get("noise_type"),
+        noise_mix_type=get("noise_mix_type"), pooling_type=get("pooling_type"),
+        pool_every_timestep=get("pool_every_timestep"), dropout=get("dropout"), bottleneck_dim=get("bottleneck_dim"),
+        neighborhood_size=get("neighborhood_size"), grid_size=get("grid_size"), batch_norm=get("batch_norm"),
+        device=device)
+    gen.load_state_dict(checkpoint["g_state"])
+    gen.train()
+    return gen
+
+
+def round4(x):
+    """np.around(x, 4) on float64 tensors (round-half-even), world_model.py:169,192."""
+    return torch.round(x * 10000.0) / 10000.0
+
+
+class VecSGANWorld(object):
+    """Batched SGANWorld: hist [E,8,N,2] float64 ring in HBM, one mcn_sgan_step per call."""
+
+    def __init__(self, generator, num_envs, num_humans, device, time_step=0.25, seed=None):
+        self.generator = generator
+        self.E, self.N = int(num_envs), int(num_humans)
+        self.device = torch.device(device)
+        self.time_step = float(time_step)
+        self.hist = torch.zeros(self.E, 8, self.N, 2, dtype=torch.float64, device=self.device)
+        self.oldest = 0
+        self.out_vel = torch.zeros(self.E, self.N, 2, dtype=torch.float64, device=self.device)
+        self._gen = torch.Generator(device="cpu")
+        if seed is not None:
+            self._gen.manual_seed(int(seed))
+
+    def reset_history(self, hist):
+        """hist: [E,8,N,2] positions, oldest frame first (datagen.py:423-430 writes the last obs_len frames)."""
+        self.hist.copy_(round4(hist.to(self.device, torch.float64)))
+        self.oldest = 0
+
+    def init_constant_velocity(self, pos, vel):
+        """8 frames ending at `pos`, walking backwards at `vel`."""
+        k = torch.arange(7, -1, -1, dtype=torch.float64, device=self.device).view(1, 8, 1, 1)
+        self.reset_history(pos.unsqueeze(1) - vel.unsqueeze(1) * (k * self.time_step))
+
+    def draw_noise(self):
+        return torch.randn(self.E, 8, generator=self._gen).to(self.device)
+
+    def __call__(self, cur_pos, noise=None):
+        """cur_pos [E,N,2] float64 -> velocities [E,N,2] float64 (a view reused by the next call)."""
+        if noise is None:
+            noise = self.draw_noise()
+        push = self.oldest
+        self.oldest = (self.oldest + 1) & 7
+        cur = cur_pos if (cur_pos.dtype == torch.float64 and cur_pos.is_contiguous()) else \
+            cur_pos.to(self.device, torch.float64).contiguous()
+        sgan_step(self.generator, self.hist, push, self.oldest, cur, noise.float().contiguous(), self.time_step,
+                  out_vel=self.out_vel)
+        return self.out_vel
+
+
+class SGANWorld(nn.Module):
+    """E = 1 drop-in (world_model.py:134-268): `sim_world(list[[px,py,vx,vy]]) -> ndarray [N,2]`.
+
+    `dataFile` is read once if it exists (the `frame<TAB>ped<TAB>x<TAB>y` cache the reference rewrites every
+    step); afterwards the history lives on the device and no file I/O happens per step."""
+
+    def __init__(self, dataFile, device, obs_len=8, pred_len=1, skip=1, delim="tab", time_step=0.4, pretrainPath=""):
+        super().__init__()
+        if obs_len != 8 or pred_len != 1:
+            raise NotImplementedError("the shipped generators use obs_len 8 and one-step prediction")
+        self.dataFile, self.device = dataFile, torch.device(device)
+        self.obs_len, self.pred_len, self.skip, self.delim = obs_len, pred_len, skip, delim
+        self.frameid = obs_len + 10
+        self.time_step = time_step
+        self.generator = None
+        self._vec = None
+        if pretrainPath != "":
+            logging.info("Loading SGAN pretrain generator: %s", pretrainPath)
+            checkpoint = torch.load(pretrainPath, map_location="cpu", weights_only=True)
+            self.generator = get_generator(checkpoint, self.device)
+
+    def _read_cache(self):
+        rows = []
+        sep = {"tab": "\t", "space": " "}.get(self.delim, self.delim)
+        with open(self.dataFile) as fh:
+            for line in fh:
+                parts = line.strip().split(sep)
+                if len(parts) == 4:
+                    rows.append([float(v) for v in parts])
+        return np.asarray(rows, np.float64)
+
+    def load_history(self, n_humans):
+        """(Re)build the device ring from the cache file (call after the driver rewrites it)."""
+        dev = self.device if self.device.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+        self._vec = VecSGANWorld(self.generator, 1, n_humans, dev, self.time_step)
+        if self.dataFile and os.path.exists(self.dataFile):
+            data = self._read_cache()
+            frames = np.unique(data[:, 0])[-8:] if len(data) else []
+            if len(frames) == 8:
+                hist = np.zeros((1, 8, n_humans, 2))
+                for t, f in enumerate(frames):
+                    sel = data[data[:, 0] == f]
+                    for row in sel:
+                        if int(row[1]) < n_humans:
+                            hist[0, t, int(row[1])] = row[2:4]
+                self._vec.reset_history(torch.from_numpy(hist))
+                return
+        self._vec = None
+
+    def forward(self, in_state):
+        self.frameid += 1
+        cur = torch.tensor([[s[0], s[1]] for s in in_state], dtype=torch.float64).unsqueeze(0)
+        n = cur.shape[1]
+        if self._vec is None or self._vec.N != n:
+            self.load_history(n)
+            if self._vec is None:          # no usable cache: start from a constant-velocity history
+                dev = self.device if self.device.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+                self._vec = VecSGANWorld(self.generator, 1, n, dev, self.time_step)
+                vel = torch.tensor([[s[2], s[3]] for s in in_state], dtype=torch.float64).unsqueeze(0)
+                self._vec.init_constant_velocity(cur.to(dev), vel.to(dev))
+        noise = torch.randn(1, 8)             # same global-stream draw as get_noise (sgan/models.py:20-25)
+        vel = self._vec(cur.to(self._vec.device), noise.to(self._vec.device))
+        return vel[0].cpu().numpy()
+
+
+def generator_from_arrays(arrays, prefix, device=None):
+    """Build a TrajectoryGenerator from plain arrays (e.g. the re-serialised zara1_8 weights in
+    tests/golden/g6_sgan.npz: keys '<prefix>__w__<state_dict key with . -> __>')."""
+    tag = prefix + "__w__"
+    sd = {k[len(tag):].replace("__", "."): torch.from_numpy(np.asarray(arrays[k])) for k in arrays.files
+          if k.startswith(tag)}
+    pooling = "pool_net" if any(k.startswith("pool_net.") for k in sd) else None
+    gen = TrajectoryGenerator(pooling_type=pooling, device=device)
+    gen.load_state_dict(sd)
+    return gen

@@ -205,7 +205,7 @@ def main():
         # the path's one exchange: episode returns + outcome codes + counts, one fused buffer
         import torch.distributed as dist
         rb = env.rollout_buffers
-        packed = torch.stack([rb["fin_return"], rb["fin_info"].double(), rb["fin_count"].double()], 1).float()
+        packed = torch.stack([rb["fin_return"][0], rb["fin_info"][0].double(), rb["fin_count"].double()], 1).float()
         gathered = torch.empty(world * E, 3, dtype=torch.float32, device=device)
         dist.all_gather_into_tensor(gathered, packed)
     barrier()
@@ -218,7 +218,7 @@ def main():
 
     rb = env.rollout_buffers
     episodes = int(rb["fin_count"].sum().item())
-    mean_ret = float(rb["fin_return"][rb["fin_count"] > 0].mean().item()) if episodes else float("nan")
+    mean_ret = float(rb["fin_return"][0][rb["fin_count"] > 0].mean().item()) if episodes else float("nan")
 
     # dominant-kernel duration, live, HIP events on the launch stream (eager launches of the same kernel)
     avg_ms, best_ms = time_kernel_events(env, acts[W:], min(K, 1000))

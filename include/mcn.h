@@ -92,11 +92,16 @@ typedef struct mcn_rollout {
     const double *disc_table;  int32_t disc_len;
     double  *ep_return;        /* [E] running sum       */
     int32_t *ep_steps;         /* [E] steps taken in the running episode */
-    /* record of the most recently finished episode per env */
-    double  *fin_return;       /* [E] */
-    double  *fin_time;         /* [E] env.global_time at the end (explorer.py:95,99) */
-    uint8_t *fin_info;         /* [E] */
+    /* records of finished episodes: with fin_slots == 1 slot 0 holds the latest episode of env e; with
+     * fin_slots > 1 episode number k < fin_slots of env e lands in slot k and later ones are not recorded */
+    double  *fin_return;       /* [fin_slots][E] */
+    double  *fin_time;         /* [fin_slots][E] env.global_time at the end (explorer.py:95,99) */
+    uint8_t *fin_info;         /* [fin_slots][E] */
     int32_t *fin_count;        /* [E] episodes finished so far */
+    int32_t  fin_slots;        /* >= 1 */
+    /* "too close" statistics (explorer.py:88-90,137-140) */
+    int32_t *danger_count;     /* [E] steps whose info was Danger, or NULL */
+    double  *danger_dist_sum;  /* [E] sum of their min_dist, or NULL */
     /* auto-reset from a pool of host-generated scenarios (bit-exact CrowdSim.reset output) */
     const double *pool_hpos, *pool_hgoal, *pool_hattr;   /* [P*N][2] */
     const double *pool_hvel;                             /* [P*N][2] or NULL (zeros) */

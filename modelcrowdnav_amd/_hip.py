@@ -44,7 +44,8 @@ class Rollout(C.Structure):
     _fields_ = [
         ("disc_table", _vp), ("disc_len", _i),
         ("ep_return", _vp), ("ep_steps", _vp),
-        ("fin_return", _vp), ("fin_time", _vp), ("fin_info", _vp), ("fin_count", _vp),
+        ("fin_return", _vp), ("fin_time", _vp), ("fin_info", _vp), ("fin_count", _vp), ("fin_slots", _i),
+        ("danger_count", _vp), ("danger_dist_sum", _vp),
         ("pool_hpos", _vp), ("pool_hgoal", _vp), ("pool_hattr", _vp), ("pool_hvel", _vp),
         ("pool_size", _i), ("next_case", _vp), ("case_stride", _i),
         ("robot_start", _d * 2), ("robot_goal", _d * 2), ("robot_theta0", _d),

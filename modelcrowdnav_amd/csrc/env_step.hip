@@ -289,14 +289,22 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(const StepParams p)
     if (leader) {
         if (p.has_roll) {
             const mcn_rollout &r = p.roll;
+            if (inf == MCN_INFO_DANGER && r.danger_count) {
+                r.danger_count[e] += 1;
+                if (r.danger_dist_sum) r.danger_dist_sum[e] += dmin;
+            }
             if (r.ep_return) {
                 const int t = r.ep_steps[e];
                 const double ret = r.ep_return[e] + r.disc_table[t < r.disc_len ? t : r.disc_len - 1] * rew;
                 if (dn) {
-                    if (r.fin_return) r.fin_return[e] = ret;
-                    if (r.fin_time)   r.fin_time[e] = (inf == MCN_INFO_TIMEOUT) ? c.time_limit : t_new;
-                    if (r.fin_info)   r.fin_info[e] = (uint8_t)inf;
-                    if (r.fin_count)  r.fin_count[e] += 1;
+                    const int k = r.fin_count ? r.fin_count[e] : 0;
+                    // fin_slots == 1: keep the latest episode; otherwise keep the first fin_slots episodes
+                    const bool keep = (r.fin_slots == 1) || (k < r.fin_slots);
+                    const long rec = (long)(r.fin_slots == 1 ? 0 : k) * p.E + e;
+                    if (keep && r.fin_return) r.fin_return[rec] = ret;
+                    if (keep && r.fin_time)   r.fin_time[rec] = (inf == MCN_INFO_TIMEOUT) ? c.time_limit : t_new;
+                    if (keep && r.fin_info)   r.fin_info[rec] = (uint8_t)inf;
+                    if (r.fin_count)  r.fin_count[e] = k + 1;
                     r.ep_return[e] = 0; r.ep_steps[e] = 0;
                 } else {
                     r.ep_return[e] = ret; r.ep_steps[e] = t + 1;

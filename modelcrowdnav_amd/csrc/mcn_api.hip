@@ -43,6 +43,7 @@ int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *
     if (!(cfg->time_step > 0)) return MCN_EINVAL;
     if (roll) {
         if (roll->ep_return && (!roll->ep_steps || !roll->disc_table || roll->disc_len <= 0)) return MCN_EINVAL;
+        if (roll->ep_return && roll->fin_slots < 1) return MCN_EINVAL;
         if (roll->pool_hpos && (!roll->pool_hgoal || !roll->pool_hattr || roll->pool_size <= 0)) return MCN_EINVAL;
     }
     mcn::StepParams p;

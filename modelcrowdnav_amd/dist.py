@@ -1,0 +1,78 @@
+"""Multi-GPU plumbing for the rollout path: one process per GPU, torch.distributed
+(backend 'nccl' = RCCL over xGMI on ROCm; 'gloo' in CPU tests).
+
+The path shards by environment: envs are independent, so there is NO per-step collective.
+The only exchange is one all_gather of finished-episode records per rollout (a few hundred KB
+at most: latency-bound on xGMI, hence a single fused buffer and a single collective).
+Seeds / scenario cases are functions of the GLOBAL env id, so results do not depend on the
+number of ranks.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_from_env(backend=None):
+    """Initialise from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run sets them)."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws <= 1 or dist.is_initialized():
+        return world()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
+    return world()
+
+
+def shard(total, rank, world_size):
+    """Contiguous [lo, hi) slice of `total` global env ids owned by `rank` (sizes differ by at most 1)."""
+    base, extra = divmod(total, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_records(returns, infos, times, counts=None):
+    """One collective: all ranks contribute [n_local] episode records and receive the
+    concatenation in rank order.  returns/times float64, infos uint8/int; all on the same device."""
+    n = returns.numel()
+    cols = [returns.reshape(-1).double(), infos.reshape(-1).double(), times.reshape(-1).double()]
+    if counts is not None:
+        cols.append(counts.reshape(-1).double())
+    packed = torch.stack(cols, 1).contiguous()
+    rank, ws = world()
+    if ws == 1:
+        out = packed
+    else:
+        sizes = torch.tensor([n], dtype=torch.int64, device=packed.device)
+        all_sizes = [torch.zeros_like(sizes) for _ in range(ws)]
+        equal = True
+        # equal shard sizes are the common case (E_total divisible by ranks): one collective, no size exchange
+        if int(os.environ.get("MCN_UNEQUAL_SHARDS", "0")):
+            dist.all_gather(all_sizes, sizes)
+            equal = len({int(s.item()) for s in all_sizes}) == 1
+        if equal:
+            out = torch.empty(ws * n, packed.shape[1], dtype=packed.dtype, device=packed.device)
+            dist.all_gather_into_tensor(out, packed)
+        else:
+            m = max(int(s.item()) for s in all_sizes)
+            pad = torch.zeros(m, packed.shape[1], dtype=packed.dtype, device=packed.device)
+            pad[:n] = packed
+            bufs = [torch.empty_like(pad) for _ in range(ws)]
+            dist.all_gather(bufs, pad)
+            out = torch.cat([b[:int(s.item())] for b, s in zip(bufs, all_sizes)], 0)
+    res = {"return": out[:, 0], "info": out[:, 1].to(torch.uint8), "time": out[:, 2]}
+    if counts is not None:
+        res["count"] = out[:, 3].to(torch.int32)
+    return res

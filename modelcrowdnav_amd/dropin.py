@@ -1,0 +1,93 @@
+"""Make the reference's import paths resolve to this build, so its drivers run unchanged.
+
+    import modelcrowdnav_amd.dropin as dropin; dropin.install()
+    # from here on:
+    #   import gym; env = gym.make('CrowdSim-v0')           -> modelcrowdnav_amd.envs.CrowdSim
+    #   from crowd_sim.envs.utils.robot import Robot         -> modelcrowdnav_amd.envs.utils.robot
+    #   from crowd_nav.policy.policy_factory import policy_factory   (has 'sarl', 'orca', 'linear', 'none')
+    #   from crowd_nav.policy.world_model import SGANWorld, get_generator
+    #   from sgan.models import TrajectoryGenerator
+
+Module names mirrored (reference file -> module here): see INTEGRATION.md.  If the real `gym` is
+importable its registry is used; otherwise a 20-line stand-in with `Env`, `make` and
+`envs.registration.register` is installed (the reference only uses those, crowd_sim/__init__.py:1-11,
+crowd_nav/test.py:64).
+"""
+import importlib
+import sys
+import types
+
+_MAP = {
+    "crowd_sim.envs": "modelcrowdnav_amd.envs",
+    "crowd_sim.envs.crowd_sim": "modelcrowdnav_amd.envs.crowd_sim",
+    "crowd_sim.envs.model_crowd_sim": "modelcrowdnav_amd.envs.model_crowd_sim",
+    "crowd_sim.envs.utils": "modelcrowdnav_amd.envs.utils",
+    "crowd_sim.envs.utils.action": "modelcrowdnav_amd.envs.utils.action",
+    "crowd_sim.envs.utils.agent": "modelcrowdnav_amd.envs.utils.agent",
+    "crowd_sim.envs.utils.human": "modelcrowdnav_amd.envs.utils.human",
+    "crowd_sim.envs.utils.info": "modelcrowdnav_amd.envs.utils.info",
+    "crowd_sim.envs.utils.robot": "modelcrowdnav_amd.envs.utils.robot",
+    "crowd_sim.envs.utils.state": "modelcrowdnav_amd.envs.utils.state",
+    "crowd_sim.envs.utils.utils": "modelcrowdnav_amd.envs.utils.utils",
+    "crowd_sim.envs.policy": "modelcrowdnav_amd.envs.policy",
+    "crowd_sim.envs.policy.policy": "modelcrowdnav_amd.envs.policy.policy",
+    "crowd_sim.envs.policy.orca": "modelcrowdnav_amd.envs.policy.orca",
+    "crowd_sim.envs.policy.linear": "modelcrowdnav_amd.envs.policy.linear",
+    "crowd_sim.envs.policy.policy_factory": "modelcrowdnav_amd.envs.policy.policy_factory",
+    "crowd_nav.policy": "modelcrowdnav_amd.policy",
+    "crowd_nav.policy.cadrl": "modelcrowdnav_amd.policy.cadrl",
+    "crowd_nav.policy.multi_human_rl": "modelcrowdnav_amd.policy.multi_human_rl",
+    "crowd_nav.policy.sarl": "modelcrowdnav_amd.policy.sarl",
+    "crowd_nav.policy.policy_factory": "modelcrowdnav_amd.policy.policy_factory",
+    "crowd_nav.policy.world_model": "modelcrowdnav_amd.policy.world_model",
+    "sgan.models": "modelcrowdnav_amd.sgan.models",
+    "sgan.utils": "modelcrowdnav_amd.sgan.utils",
+}
+
+_REGISTRY = {}
+
+
+def _gym_shim():
+    gym = types.ModuleType("gym")
+
+    class Env(object):
+        pass
+
+    def register(id, entry_point, **kw):
+        _REGISTRY[id] = entry_point
+
+    def make(id, **kw):
+        mod, cls = _REGISTRY[id].split(":")
+        return getattr(importlib.import_module(mod), cls)(**kw)
+
+    envs = types.ModuleType("gym.envs")
+    reg = types.ModuleType("gym.envs.registration")
+    reg.register = register
+    gym.Env, gym.make, gym.envs, envs.registration = Env, make, envs, reg
+    return {"gym": gym, "gym.envs": envs, "gym.envs.registration": reg}
+
+
+def install():
+    try:
+        import gym  # noqa: F401
+        from gym.envs.registration import register
+    except ImportError:
+        sys.modules.update(_gym_shim())
+        from gym.envs.registration import register
+    for pkg in ("crowd_sim", "crowd_nav", "sgan"):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = []
+            sys.modules[pkg] = m
+    for alias, target in _MAP.items():
+        mod = importlib.import_module(target)
+        sys.modules[alias] = mod
+        parent, _, leaf = alias.rpartition(".")
+        setattr(sys.modules[parent], leaf, mod)
+    # crowd_sim/__init__.py:3-11
+    for env_id, cls in (("CrowdSim-v0", "CrowdSim"), ("ModelCrowdSim-v0", "ModelCrowdSim")):
+        try:
+            register(id=env_id, entry_point="crowd_sim.envs:" + cls)
+        except Exception:            # already registered with a real gym
+            pass
+    return sorted(_MAP)

@@ -236,7 +236,7 @@ class VecCrowdSim(object):
         return self.step(actions, update=False)
 
     # ---------------------------------------------------------------- fused rollout bookkeeping
-    def attach_rollout(self, gamma, pool=None, case_stride=1, first_cases=None):
+    def attach_rollout(self, gamma, pool=None, case_stride=1, first_cases=None, fin_slots=1):
         """Enable Explorer-style return accounting (explorer.py:124) and, when `pool` ([P,N,9]
         host scenarios) is given, in-kernel auto-reset from that HBM-resident pool."""
         E, dev = self.num_envs, self.device
@@ -247,13 +247,16 @@ class VecCrowdSim(object):
         t["disc"] = torch.from_numpy(disc).to(dev)
         t["ep_return"] = torch.zeros(E, dtype=torch.float64, device=dev)
         t["ep_steps"] = torch.zeros(E, dtype=torch.int32, device=dev)
-        t["fin_return"] = torch.zeros(E, dtype=torch.float64, device=dev)
-        t["fin_time"] = torch.zeros(E, dtype=torch.float64, device=dev)
-        t["fin_info"] = torch.zeros(E, dtype=torch.uint8, device=dev)
+        t["fin_return"] = torch.zeros(fin_slots, E, dtype=torch.float64, device=dev)
+        t["fin_time"] = torch.zeros(fin_slots, E, dtype=torch.float64, device=dev)
+        t["fin_info"] = torch.zeros(fin_slots, E, dtype=torch.uint8, device=dev)
         t["fin_count"] = torch.zeros(E, dtype=torch.int32, device=dev)
+        t["danger_count"] = torch.zeros(E, dtype=torch.int32, device=dev)
+        t["danger_dist_sum"] = torch.zeros(E, dtype=torch.float64, device=dev)
         r = _hip.Rollout()
-        r.disc_table, r.disc_len = _hip.ptr(t["disc"]), horizon
-        for k in ("ep_return", "ep_steps", "fin_return", "fin_time", "fin_info", "fin_count"):
+        r.disc_table, r.disc_len, r.fin_slots = _hip.ptr(t["disc"]), horizon, int(fin_slots)
+        for k in ("ep_return", "ep_steps", "fin_return", "fin_time", "fin_info", "fin_count", "danger_count",
+                  "danger_dist_sum"):
             setattr(r, k, _hip.ptr(t[k]))
         if pool is not None:
             pool = np.asarray(pool, np.float64)
@@ -289,6 +292,7 @@ class CrowdSim(object):
     """
     metadata = {"render.modes": ["human"]}
     _vec_cls = VecCrowdSim
+    _tracks_human_times = True
 
     def __init__(self, device=None):
         self._vec = None
@@ -411,10 +415,10 @@ class CrowdSim(object):
         v = self._vec
         robot = v.robot
         self._push_host_state()
-        track = len(self.human_times) == len(self.humans)
+        track = self._tracks_human_times and len(self.human_times) == len(self.humans)
         v.track_human_times = track
         v.export_human_actions = True
-        ob, reward, done, info = v.step(self._action_tensor(action), update=update)
+        ob, reward, done, info = self._vec_step(self._action_tensor(action), update)
         pos, vel = ob.pos[0].cpu().tolist(), ob.vel[0].cpu().tolist()
         reward, done, code = float(reward.item()), bool(done.item()), int(info.item())
         info_obj = I.from_code(code, float(v.dmin.item()))
@@ -437,6 +441,9 @@ class CrowdSim(object):
         else:
             out = [ObservableState(p[0], p[1], w[0], w[1], h.radius) for h, p, w in zip(self.humans, pos, vel)]
         return out, reward, done, info_obj
+
+    def _vec_step(self, actions, update):
+        return self._vec.step(actions, update=update)
 
     def render(self, mode="human", output_file=None, render_weight=False):
         raise NotImplementedError("render is matplotlib host tooling, out of scope for this build (SURVEY.md 2)")

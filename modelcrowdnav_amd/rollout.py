@@ -1,0 +1,114 @@
+"""Batched Explorer: run k evaluation episodes over E environments resident in HBM
+(reference: crowd_nav/utils/explorer.py:36-151, run_k_episodes).
+
+The reference loop is `for i in range(k): ob = env.reset(); while not done: a = robot.act(ob);
+ob, r, done, info = env.step(a)`.  Here episode i runs in env (i mod E): every env starts with case
+`first + e`, and when it finishes an episode env_step.hip resets it in place from an HBM-resident pool
+to case `+E`, so the k episodes use exactly the cases the sequential loop would have used.  Per step
+there is one policy launch and one env launch, no host synchronisation; discounted returns
+(explorer.py:124), outcomes, navigation times and the "too close" statistics (:88-90) are accumulated
+in-kernel.  With several ranks, envs are sharded by global env id and the records are combined by ONE
+all_gather (dist.gather_records).
+"""
+import logging
+
+import numpy as np
+import torch
+
+from . import _hip
+from . import dist as mdist
+from .envs import scenarios as S
+
+
+def average(xs):
+    return sum(xs) / len(xs) if xs else 0
+
+
+class VecExplorer(object):
+    def __init__(self, env, robot, device=None, gamma=0.9, policy=None):
+        self.env, self.robot, self.gamma = env, robot, gamma
+        self.device = device or env.device
+        self.policy = policy if policy is not None else robot.policy
+
+    def _actions(self, step_actions):
+        if step_actions is not None:
+            return step_actions
+        a, _ = self.policy.predict_batch(self.env)
+        return a
+
+    def run_k_episodes(self, k, phase, episode=None, print_failure=False, returnRate=True, returnNav=False,
+                       action_fn=None, max_steps=None, total_envs=None):
+        """Returns what Explorer.run_k_episodes returns (explorer.py:146-151):
+        (avg cumulative reward, success rate, collision rate, timeout rate[, avg nav time])
+        or counts instead of rates when returnRate is False.  `action_fn(env, t) -> [E,2]` overrides the
+        policy (e.g. a random-action baseline)."""
+        env = self.env
+        rank, ws = mdist.world()
+        E_local = env.num_envs
+        E_total = total_envs if total_envs is not None else E_local * ws
+        lo = rank * E_local
+        if hasattr(self.policy, "set_phase"):
+            self.policy.set_phase(phase)
+        n, rule = env._phase_rule(phase)
+        first = env.case_counter[phase]
+        size = env.case_size[phase]
+        rounds = -(-k // E_total)                               # episodes per env (ceil)
+        cases = [(first + i) % size for i in range(rounds * E_total)]
+        uniq = sorted(set(cases))
+        pool = S.scenario_pool(env.spec(), phase, uniq, n, rule)
+        slot_of = {c: j for j, c in enumerate(uniq)}
+        # env e of this rank plays global episodes (lo + e) + r * E_total, r = 0..rounds-1
+        mine = np.array([[slot_of[cases[(lo + e) + r * E_total]] for r in range(rounds)] for e in range(E_local)])
+        env.load_scenarios(pool[mine[:, 0]])
+        stride = 0
+        if rounds > 1:
+            # pool slots advance by a constant stride when cases are consecutive (the usual situation)
+            d = (mine[:, 1] - mine[:, 0]) % len(uniq)
+            if not np.all(d == d[0]) or any(np.any((mine[:, r + 1] - mine[:, r]) % len(uniq) != d[0])
+                                            for r in range(rounds - 1)):
+                raise NotImplementedError("non-uniform case stride (k wraps the case list unevenly)")
+            stride = int(d[0])
+        bufs = env.attach_rollout(self.gamma, pool=pool, case_stride=stride,
+                                  first_cases=(mine[:, 1] if rounds > 1 else mine[:, 0]), fin_slots=rounds)
+        horizon = int(round(env.time_limit / env.time_step)) + 2
+        limit = max_steps if max_steps is not None else rounds * horizon
+        t = 0
+        while t < limit:
+            a = action_fn(env, t) if action_fn is not None else self._actions(None)
+            env.step(a)
+            t += 1
+            if t % 32 == 0 and int(bufs["fin_count"].min().item()) >= rounds:
+                break
+        if int(bufs["fin_count"].min().item()) < rounds:
+            raise RuntimeError("rollout did not finish %d episodes per env within %d steps" % (rounds, limit))
+        env.case_counter[phase] = (first + k) % size
+        # records in global episode order: episode g = r * E_total + global_env
+        rec = mdist.gather_records(bufs["fin_return"].t().contiguous(), bufs["fin_info"].t().contiguous(),
+                                   bufs["fin_time"].t().contiguous())
+        ret = rec["return"].view(-1, rounds).cpu().numpy()        # [E_total, rounds]
+        inf = rec["info"].view(-1, rounds).cpu().numpy()
+        tim = rec["time"].view(-1, rounds).cpu().numpy()
+        order = [(g % E_total, g // E_total) for g in range(k)]
+        returns = [float(ret[e, r]) for e, r in order]
+        infos = [int(inf[e, r]) for e, r in order]
+        times = [float(tim[e, r]) for e, r in order]
+        success = sum(1 for c in infos if c == _hip.INFO_REACHGOAL)
+        collision = sum(1 for c in infos if c == _hip.INFO_COLLISION)
+        timeout = sum(1 for c in infos if c == _hip.INFO_TIMEOUT)
+        assert success + collision + timeout == k
+        success_times = [tm for tm, c in zip(times, infos) if c == _hip.INFO_REACHGOAL]
+        avg_nav_time = sum(success_times) / len(success_times) if success_times else env.time_limit
+        extra = "" if episode is None else "in episode {} ".format(episode)
+        logging.info("%-5s %shas success rate: %.2f, collision rate: %.2f, nav time: %.2f, total reward: %.4f",
+                     phase.upper(), extra, success / k, collision / k, avg_nav_time, average(returns))
+        if print_failure:
+            logging.info("Collision cases: %s", " ".join(str(i) for i, c in enumerate(infos) if c == _hip.INFO_COLLISION))
+            logging.info("Timeout cases: %s", " ".join(str(i) for i, c in enumerate(infos) if c == _hip.INFO_TIMEOUT))
+        self.last_records = dict(returns=returns, infos=infos, times=times,
+                                 danger_steps=int(bufs["danger_count"].sum().item()))
+        env.detach_rollout()
+        if returnRate and returnNav:
+            return average(returns), success / k, collision / k, (k - success - collision) / k, avg_nav_time
+        if returnRate:
+            return average(returns), success / k, collision / k, (k - success - collision) / k
+        return average(returns), success, collision, (k - success - collision)

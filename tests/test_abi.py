@@ -30,7 +30,8 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(_hip.EnvState) == 11 * 8
     assert ctypes.sizeof(_hip.EnvOut) == 8 * 8
     r = _hip.Rollout
-    assert r.disc_len.offset == 8 and r.ep_return.offset == 16 and r.pool_size.offset == 96
+    assert r.disc_len.offset == 8 and r.ep_return.offset == 16 and r.fin_slots.offset == 64
+    assert r.danger_count.offset == 72 and r.pool_hpos.offset == 88 and r.pool_size.offset == 120
     assert r.robot_start.offset % 8 == 0
 
 

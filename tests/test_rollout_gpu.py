@@ -1,0 +1,174 @@
+"""GPU: the callers either side of the step kernel -- batched Explorer, the E = 1 gym views driven like the
+reference's drivers drive them (test.py:64-109, explorer.py:54-125), ModelCrowdSim with a world model."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cport  # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+
+def _goal_seeking(env, t):
+    """Deterministic, state-only robot policy whose arithmetic is exact on any IEEE machine: move at +-0.6 along
+    each axis according to the sign of the remaining goal offset (0 inside a 0.2 band)."""
+    import torch
+    d = env.rgoal - env.rpos
+    v, z = torch.full_like(d, 0.6), torch.zeros_like(d)          # float64 constants (python scalars would be f32)
+    return (torch.where(d > 0.2, v, z) - torch.where(d < -0.2, v, z)).contiguous()
+
+
+def _oracle_episode(scen, gamma=0.9):
+    st = cport.EnvState(1, scen.shape[0])
+    st.hpx[0], st.hpy[0], st.hgx[0], st.hgy[0] = scen[:, 0], scen[:, 1], scen[:, 2], scen[:, 3]
+    st.hr[0], st.hvpref[0] = scen[:, 7], scen[:, 8]
+    st.rpy[0], st.rgy[0], st.rr[0] = -4.0, 4.0, 0.3
+    cfg = cport.default_cfg()
+    rewards = []
+    while True:
+        dx, dy = st.rgx[0] - st.rpx[0], st.rgy[0] - st.rpy[0]
+        ax = 0.6 if dx > 0.2 else (-0.6 if dx < -0.2 else 0.0)
+        ay = 0.6 if dy > 0.2 else (-0.6 if dy < -0.2 else 0.0)
+        out = cport.env_step(cfg, st, np.array([ax]), np.array([ay]))
+        rewards.append(float(out["reward"][0]))
+        if out["done"][0]:
+            tm = 25.0 if out["info"][0] == cport.INFO_TIMEOUT else float(st.gtime[0])
+            ret = sum([pow(gamma, t * 0.25 * 1.0) * r for t, r in enumerate(rewards)])
+            return ret, int(out["info"][0]), tm
+
+
+def test_vec_explorer_equals_sequential_loop():
+    """k episodes over E < k envs with in-kernel auto-reset == the reference's one-at-a-time loop."""
+    from modelcrowdnav_amd.envs import scenarios as S
+    from modelcrowdnav_amd.rollout import VecExplorer
+    E, N, k = 32, 5, 70
+    env = H.make_vec_env(E, N)
+    env.track_human_times = False; env.export_human_actions = False
+    ex = VecExplorer(env, env.robot, gamma=0.9, policy=object())
+    avg, sr, cr, tr, nav = ex.run_k_episodes(k, "test", action_fn=_goal_seeking, returnNav=True)
+    want = [_oracle_episode(S.scenario_for_case(env.spec(), "test", c, N, "circle_crossing")) for c in range(k)]
+    got = ex.last_records
+    assert got["infos"] == [w[1] for w in want]
+    bad = [i for i in range(k) if got["returns"][i] != want[i][0] or got["times"][i] != want[i][2]]
+    assert not bad, (bad, [got["returns"][i] for i in bad], [want[i][0] for i in bad])
+    assert avg == sum([w[0] for w in want]) / k
+    assert len(set(got["infos"])) > 1, "test should exercise more than one outcome"
+    assert env.case_counter["test"] == k % 500
+
+
+def test_crowdsim_e1_with_orca_robot_matches_oracle():
+    """BASELINE config 1 plumbing: CrowdSim gym surface, ORCA humans, ORCA robot (test.py --policy orca)."""
+    import torch
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.envs import CrowdSim
+    from modelcrowdnav_amd.envs.utils.robot import Robot
+    from modelcrowdnav_amd.envs.policy.policy_factory import policy_factory
+    from modelcrowdnav_amd.envs import scenarios as S
+    cfg = configs.env_config()
+    env = CrowdSim()
+    env.configure(cfg)
+    robot = Robot(cfg, "robot")
+    pol = policy_factory["orca"]()
+    pol.configure(cfg)
+    robot.set_policy(pol)
+    env.set_robot(robot)
+    pol.set_phase("test"); pol.set_device(torch.device("cuda", 0)); pol.set_env(env)
+    for case in (0, 3):
+        ob = env.reset("test", case)
+        scen = S.scenario_for_case(S.ScenarioSpec(), "test", case, 5, "circle_crossing")
+        st = cport.EnvState(1, 5)
+        st.hpx[0], st.hpy[0], st.hgx[0], st.hgy[0] = scen[:, 0], scen[:, 1], scen[:, 2], scen[:, 3]
+        st.hr[0], st.hvpref[0] = scen[:, 7], scen[:, 8]
+        st.rpy[0], st.rgy[0], st.rr[0] = -4.0, 4.0, 0.3
+        ocfg = cport.default_cfg()
+        done, steps = False, 0
+        while not done:
+            action = robot.act(ob)
+            # oracle robot: ORCA over all humans (orca.py:82-132), self radius r + 0.01, max speed v_pref
+            opos = np.stack([st.hpx[0], st.hpy[0]], 1); ovel = np.stack([st.hvx[0], st.hvy[0]], 1)
+            ov = cport.orca_agent((st.rpx[0], st.rpy[0]), (st.rvx[0], st.rvy[0]), np.float32(0.3 + 0.01), 1.0,
+                                  (np.float32(st.rgx[0] - st.rpx[0]), np.float32(st.rgy[0] - st.rpy[0])),
+                                  opos, ovel, (st.hr[0] + 0.01).astype(np.float32))
+            assert (np.float32(action.vx), np.float32(action.vy)) == ov, (case, steps)
+            ob, reward, done, info = env.step(action)
+            ref = cport.env_step(ocfg, st, np.array([float(ov[0])]), np.array([float(ov[1])]))
+            assert reward == ref["reward"][0] and done == bool(ref["done"][0]) and info.code == ref["info"][0]
+            assert [o.px for o in ob] == st.hpx[0].tolist() and [o.vy for o in ob] == st.hvy[0].tolist()
+            assert env.global_time == st.gtime[0]
+            steps += 1
+        assert steps > 10
+        assert len(env.states) == steps
+
+
+def test_crowdsim_e1_sarl_episode_matches_reference(golden_dir):
+    """G7: reference CrowdSim + SARL (seeded weights) episodes; this build's CrowdSim + SARL must take the same
+    actions and collect the same rewards step by step."""
+    import torch
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.envs import CrowdSim
+    from modelcrowdnav_amd.envs.utils.robot import Robot
+    from modelcrowdnav_amd.policy.policy_factory import policy_factory
+    g = np.load(os.path.join(golden_dir, "g7_episode.npz"))
+    for seed, N in ((0, 5), (0, 10)):
+        cfg = configs.env_config(**{"sim.human_num": N})
+        env = CrowdSim()
+        env.configure(cfg)
+        robot = Robot(cfg, "robot")
+        pol = policy_factory["sarl"]()
+        pol.configure(configs.policy_config())
+        pol.kinematics = "holonomic"
+        pref = "ep%d_N%d_w__" % (seed, N)
+        pol.model.load_state_dict({k[len(pref):].replace("__", "."): torch.from_numpy(g[k]) for k in g.files
+                                   if k.startswith(pref)})
+        robot.set_policy(pol)
+        env.set_robot(robot)
+        pol.set_phase("test"); pol.set_device(torch.device("cuda", 0)); pol.set_env(env)
+        for case in (0, 1):
+            key = "ep%d_N%d_c%d_" % (seed, N, case)
+            ob = env.reset("test", case)
+            done, t, rewards = False, 0, []
+            while not done:
+                action = robot.act(ob)
+                want = g[key + "actions"][t]
+                assert (action.vx, action.vy) == tuple(want), (seed, N, case, t)
+                ob, reward, done, info = env.step(action)
+                assert reward == g[key + "rewards"][t] and info.code == g[key + "info"][t]
+                rewards.append(reward)
+                t += 1
+            assert t == len(g[key + "rewards"])
+            ret = sum([pow(0.9, k * robot.time_step * robot.v_pref) * r for k, r in enumerate(rewards)])
+            assert ret == float(g[key + "return"])
+            assert env.global_time == float(g[key + "time"])
+
+
+def test_model_crowd_sim_with_sgan_world(golden_dir):
+    """BASELINE config 4 shape (reduced E): VecModelCrowdSim + VecSGANWorld + SARL robot; the env must move the
+    humans exactly by the world model's velocities, and the E = 1 ModelCrowdSim view must agree with env 0."""
+    import torch
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.envs import VecModelCrowdSim
+    from modelcrowdnav_amd.policy.world_model import VecSGANWorld, generator_from_arrays
+    from modelcrowdnav_amd.policy.sarl import SARL
+    dev = torch.device("cuda", 0)
+    E, N = 64, 10
+    env = H.make_vec_env(E, N, cls=VecModelCrowdSim)
+    env.export_human_actions = True
+    env.reset("test", test_cases=list(range(E)))
+    gen = generator_from_arrays(np.load(os.path.join(golden_dir, "g6_sgan.npz")), "p", dev)
+    world = VecSGANWorld(gen, E, N, dev, time_step=env.time_step, seed=0)
+    world.init_constant_velocity(env.hpos, env.hvel)
+    env.sim_world = world
+    torch.manual_seed(0)
+    pol = SARL(); pol.configure(configs.policy_config()); pol.kinematics = "holonomic"
+    pol.set_device(dev); pol.set_phase("test"); pol.time_step = env.time_step
+    for t in range(12):
+        before = env.hpos.clone()
+        actions, _ = pol.predict_batch(env)
+        ob, reward, done, info = env.step(actions)
+        vel = world.out_vel
+        assert torch.equal(env.hvel, vel)
+        assert torch.equal(env.hpos, before + vel * env.time_step)
+        assert torch.equal(env.hh_count, torch.zeros_like(env.hh_count))         # ModelCrowdSim does not count
+    assert float(env.gtime[0]) == 12 * 0.25

@@ -61,9 +61,14 @@ struct GroupCand {
 
 // NT > 0: humans per env known at compile time (register-resident ORCA, constant lane->(env,human)
 // split); NT == 0: run-time N (LDS-resident lines), any N <= MCN_MAX_HUMANS.  VIS: robot visible to humans.
-template <int BLOCK, int NT, int VIS>
-__global__ __launch_bounds__(BLOCK) void env_step_kernel(const StepParams p)
+// MODE: MCN_HUMANS_* fixed at compile time, so the given-velocity / linear variants carry no ORCA registers,
+// no neighbour staging and no goal loads (they are pure streaming kernels and want maximum occupancy).
+// HH_T: 0 never count overlaps, 1 always, 2 decide at run time from cfg.count_hh.
+template <int BLOCK, int NT, int VIS, int MODE, int HH_T>
+__global__ __launch_bounds__(BLOCK)     // (forcing 8 waves/SIMD on the streaming variants spills and is 1.5x slower)
+void env_step_kernel(const StepParams p)
 {
+    constexpr bool kStageHumans = (MODE == MCN_HUMANS_ORCA) || (HH_T != 0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // carve (all offsets multiples of 16 B)
     float4  *sL      = reinterpret_cast<float4 *>(smem);                       // [nl_cap][BLOCK]
@@ -85,7 +90,14 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(const StepParams p)
     const int g = lane / N;
     const int h = lane - g * N;
     const int slot = wave * G + g;                          // env slot inside the block
-    const long e = (long)blockIdx.x * ((BLOCK / 64) * G) + slot;
+    // XCD-aware chunking: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), each with a
+    // private L2.  Give every XCD one contiguous range of envs so that the cache lines of the narrow per-env
+    // outputs (u8 done/info, i32 counters), which straddle neighbouring workgroups, are completed inside ONE
+    // L2 instead of being written back partially from several.  Bijective for any grid size.
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+    const unsigned qq = nb >> 3, rr_ = nb & 7u;
+    const unsigned chunk = (xcd < rr_ ? xcd * (qq + 1) : rr_ * (qq + 1) + (xcd - rr_) * qq) + idx;
+    const long e = (long)chunk * ((BLOCK / 64) * G) + slot;
     const bool active = (g < G) && (e < p.E);
     const bool leader = active && (h == 0);
     const long a = active ? e * N + h : 0;
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(const StepParams p)
     if (active) {
         pos  = reinterpret_cast<const double2 *>(p.st.hpos)[a];
         vel  = reinterpret_cast<const double2 *>(p.st.hvel)[a];
-        goal = reinterpret_cast<const double2 *>(p.st.hgoal)[a];
+        if constexpr (MODE != MCN_HUMANS_GIVEN) goal = reinterpret_cast<const double2 *>(p.st.hgoal)[a];
         attr = reinterpret_cast<const double2 *>(p.st.hattr)[a];
     }
     double2 rpos = make_double2(0, 0), rvel = rpos, rgoal = rpos, rattr = rpos, act = rpos;
@@ -124,23 +136,27 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(const StepParams p)
     // ---- stage neighbour tiles in LDS ----
     const float fpx = (float)pos.x, fpy = (float)pos.y, fvx = (float)vel.x, fvy = (float)vel.y;
     const float frad = (float)(attr.x + 0.01 + c.orca_safety_space);
-    sAgF[tid] = make_float4(fpx, fpy, fvx, fvy);
-    sRadF[tid] = frad;
-    sPosD[tid] = pos;
-    sRadD[tid] = attr.x;
+    if constexpr (kStageHumans) {
+        sAgF[tid] = make_float4(fpx, fpy, fvx, fvy);
+        sRadF[tid] = frad;
+        sPosD[tid] = pos;
+        sRadD[tid] = attr.x;
+    }
     if (leader) {
         sRobPos[slot] = rpos;
         sRobAct[slot] = eff;
         sRobRad[slot] = rattr.x;
-        sRobF[slot] = make_float4((float)rpos.x, (float)rpos.y, (float)rvel.x, (float)rvel.y);
-        sRobRadF[slot] = (float)(rattr.x + 0.01 + c.orca_safety_space);
+        if constexpr (MODE == MCN_HUMANS_ORCA) {
+            sRobF[slot] = make_float4((float)rpos.x, (float)rpos.y, (float)rvel.x, (float)rvel.y);
+            sRobRadF[slot] = (float)(rattr.x + 0.01 + c.orca_safety_space);
+        }
     }
     __syncthreads();
 
     // ---- K1: human action ----
     double hax = 0, hay = 0;
     if (active) {
-        if (c.human_policy == MCN_HUMANS_ORCA) {
+        if constexpr (MODE == MCN_HUMANS_ORCA) {
             float ox, oy;
             if constexpr (NT > 0) {
                 constexpr int NC = NT - 1 + VIS;
@@ -166,7 +182,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(const StepParams p)
                            c.orca_neighbor_dist, c.orca_max_neighbors, c.orca_time_horizon, (float)dt, L, ox, oy);
             }
             hax = (double)ox; hay = (double)oy;
-        } else if (c.human_policy == MCN_HUMANS_LINEAR) {
+        } else if constexpr (MODE == MCN_HUMANS_LINEAR) {
             const double th = atan2(goal.y - pos.y, goal.x - pos.x);
             hax = cos(th) * attr.y; hay = sin(th) * attr.y;
         } else {
@@ -186,7 +202,10 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(const StepParams p)
         const double ex = px + vx * dt, ey = py + vy * dt;
         cd = p2s_origin(px, py, ex, ey) - attr.x - rr;
     }
-    if (c.count_hh) {
+    bool do_hh = false;
+    if constexpr (HH_T == 1) do_hh = true;
+    if constexpr (HH_T == 2) do_hh = c.count_hh != 0;
+    if (do_hh) {
         // Overlap test sqrt(dx^2+dy^2) - ri - rj < 0 (crowd_sim.py:371-374).  A float32 pre-filter on the
         // staged tile decides every pair that is not within 1e-3 of touching; only if some lane of the
         // wavefront holds a borderline pair does the wave take the exact float64 path.
@@ -281,7 +300,8 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(const StepParams p)
             reinterpret_cast<double2 *>(p.st.hvel)[a] = make_double2(hax, hay);
             if (c.track_human_times && p.st.human_times) {
                 // crowd_sim.py:418-421 / agent.py:137-138
-                if (p.st.human_times[a] == 0 && norm2(npx - goal.x, npy - goal.y) < attr.x)
+                const double2 gl = reinterpret_cast<const double2 *>(p.st.hgoal)[a];
+                if (p.st.human_times[a] == 0 && norm2(npx - gl.x, npy - gl.y) < attr.x)
                     p.st.human_times[a] = t_new;
             }
         }
@@ -334,27 +354,35 @@ static size_t step_smem_bytes(int block, int nl_cap)
     return (size_t)block * (16u * nl_cap + 16 + 16 + 16 + 16 + 16 + 8 + 8 + 4 + 4);
 }
 
-template <int BLOCK, int NT, int VIS>
+template <int BLOCK, int NT, int VIS, int MODE, int HH_T>
 static void launch_one(const StepParams &p, int blocks, hipStream_t stream)
 {
-    const size_t sm = step_smem_bytes(BLOCK, NT ? 0 : p.nl_cap);
-    hipLaunchKernelGGL((env_step_kernel<BLOCK, NT, VIS>), dim3(blocks), dim3(BLOCK), sm, stream, p);
+    const size_t sm = step_smem_bytes(BLOCK, (NT || MODE != MCN_HUMANS_ORCA) ? 0 : p.nl_cap);
+    hipLaunchKernelGGL((env_step_kernel<BLOCK, NT, VIS, MODE, HH_T>), dim3(blocks), dim3(BLOCK), sm, stream, p);
 }
 
 template <int BLOCK>
-static bool dispatch(const StepParams &p, int blocks, hipStream_t stream)
+static void dispatch(const StepParams &p, int blocks, hipStream_t stream)
 {
     const int vis = p.cfg.robot_visible ? 1 : 0;
-    // register-resident ORCA specialisations for the crowd sizes the reference trains and tests on
-    // (human_num 5 / 10 in the configs, 5,7,9 in test_mul_env.py:31-33, 1..5 in the 'mixed' rule)
-#define MCN_CASE(NT_) case NT_: if (vis) launch_one<BLOCK, NT_, 1>(p, blocks, stream); else launch_one<BLOCK, NT_, 0>(p, blocks, stream); return true;
-    switch (p.N) {
-        MCN_CASE(1) MCN_CASE(2) MCN_CASE(3) MCN_CASE(4) MCN_CASE(5) MCN_CASE(6) MCN_CASE(7) MCN_CASE(8) MCN_CASE(9) MCN_CASE(10)
-        default: break;
-    }
+    if (p.cfg.human_policy == MCN_HUMANS_ORCA) {
+        // register-resident ORCA specialisations for the crowd sizes the reference trains and tests on
+        // (human_num 5 / 10 in the configs, 5,7,9 in test_mul_env.py:31-33, 1..5 in the 'mixed' rule)
+#define MCN_CASE(NT_) case NT_: if (vis) launch_one<BLOCK, NT_, 1, MCN_HUMANS_ORCA, 2>(p, blocks, stream); \
+                               else     launch_one<BLOCK, NT_, 0, MCN_HUMANS_ORCA, 2>(p, blocks, stream); return;
+        switch (p.N) {
+            MCN_CASE(1) MCN_CASE(2) MCN_CASE(3) MCN_CASE(4) MCN_CASE(5) MCN_CASE(6) MCN_CASE(7) MCN_CASE(8) MCN_CASE(9) MCN_CASE(10)
+            default: break;
+        }
 #undef MCN_CASE
-    launch_one<BLOCK, 0, 0>(p, blocks, stream);     // run-time N, LDS-resident lines
-    return true;
+        launch_one<BLOCK, 0, 0, MCN_HUMANS_ORCA, 2>(p, blocks, stream);     // run-time N, LDS-resident lines
+    } else if (p.cfg.human_policy == MCN_HUMANS_GIVEN) {
+        if (p.cfg.count_hh) launch_one<BLOCK, 0, 0, MCN_HUMANS_GIVEN, 1>(p, blocks, stream);
+        else                launch_one<BLOCK, 0, 0, MCN_HUMANS_GIVEN, 0>(p, blocks, stream);
+    } else {
+        if (p.cfg.count_hh) launch_one<BLOCK, 0, 0, MCN_HUMANS_LINEAR, 1>(p, blocks, stream);
+        else                launch_one<BLOCK, 0, 0, MCN_HUMANS_LINEAR, 0>(p, blocks, stream);
+    }
 }
 
 int launch_env_step(const StepParams &p, hipStream_t stream)

@@ -83,4 +83,85 @@ __device__ __forceinline__ void dense_acc(const f32x4 (&in)[KT], const f32x4 (&i
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// LDS-staged variant: the workgroup's waves all run the same layer on different batch tiles, so the
+// weight fragments are fetched from L2 ONCE per workgroup into a double-buffered LDS stage (one chunk =
+// the fragments of two output tiles, <= 20 KiB) and every wave reads its A operands from there with
+// conflict-free ds_read_b128 (consecutive lanes, consecutive 16-B slots).  While chunk c is being
+// multiplied, the loads of chunk c+1 are already in flight (issued before the MFMAs, written to the other
+// buffer after them); one barrier per chunk.  Every thread of the workgroup must call this uniformly.
+constexpr int kStageThreads = 512;
+constexpr int kStageFloat4 = 2 * 10 * 64;        // largest chunk: 2 output tiles x KT = 10 input tiles
+
+struct WeightStage {
+    float4 *buf;      // LDS, 2 * kStageFloat4 float4
+    int tid;          // threadIdx.x, 0 .. kStageThreads-1
+};
+
+template <int KT, int NT, bool RELU, bool HAS_INIT>
+__device__ __forceinline__ void dense_staged(const f32x4 (&in)[KT], const f32x4 *init, f32x4 (&out)[NT],
+                                             const float4 *__restrict__ wf, const float4 *__restrict__ bf,
+                                             const WeightStage &S, int lane)
+{
+    constexpr int CH = 2 * KT * 64;                       // float4 per full chunk
+    constexpr int TOTAL = NT * KT * 64;
+    constexpr int NCH = (NT + 1) / 2;
+    constexpr int PER = (CH + kStageThreads - 1) / kStageThreads;
+    float4 pre[PER];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = S.tid + k * kStageThreads;
+            pre[k] = (i < CH && c * CH + i < TOTAL) ? wf[c * CH + i] : make_float4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int b) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = S.tid + k * kStageThreads;
+            if (i < CH) S.buf[b * kStageFloat4 + i] = pre[k];
+        }
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int n = 2 * c;
+        const bool two = (n + 1 < NT);
+        if (c + 1 < NCH) gload(c + 1);
+        const float4 *w = S.buf + (c & 1) * kStageFloat4;
+        f32x4 a0, a1 = {0, 0, 0, 0};
+        if (HAS_INIT) {
+            a0 = init[n];
+            if (two) a1 = init[n + 1];
+        } else {
+            { const float4 b = bf[n * 64 + lane]; a0 = (f32x4){b.x, b.y, b.z, b.w}; }
+            if (two) { const float4 b = bf[(n + 1) * 64 + lane]; a1 = (f32x4){b.x, b.y, b.z, b.w}; }
+        }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const float4 w0 = w[t * 64 + lane];
+            float4 w1 = make_float4(0, 0, 0, 0);
+            if (two) w1 = w[(KT + t) * 64 + lane];
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, in[t][0], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, in[t][0], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, in[t][1], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, in[t][1], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, in[t][2], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, in[t][2], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, in[t][3], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, in[t][3], a1, 0, 0, 0);
+        }
+        if (RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a0[r] = fmaxf(a0[r], 0.0f); a1[r] = fmaxf(a1[r], 0.0f); }
+        }
+        out[n] = a0;
+        if (two) out[n + 1] = a1;
+        if (c + 1 < NCH) lstore((c + 1) & 1);
+        __syncthreads();
+    }
+}
+
 }  // namespace mcn

@@ -72,17 +72,19 @@ struct SarlParams {
 
 __device__ __forceinline__ double norm2d(double x0, double x1) { return sqrt(fma(x1, x1, x0 * x0)); }
 
-constexpr int kSarlWaves = 4;     // wavefronts per workgroup (independent; only a dispatch granule)
+constexpr int kSarlWaves = kStageThreads / 64;     // 8 wavefronts share one LDS weight stage (2 per SIMD)
 
-__global__ __launch_bounds__(kSarlWaves * 64) void sarl_value_kernel(const SarlParams p)
+__global__ __launch_bounds__(kSarlWaves * 64, 2) void sarl_value_kernel(const SarlParams p)
 {
+    __shared__ float4 s_stage[2 * kStageFloat4];
+    const WeightStage S{s_stage, (int)threadIdx.x};
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const long gw = (long)blockIdx.x * kSarlWaves + wave;       // global wave id
     const int j = lane & 15, q = lane >> 4;
     const long npairs = (long)p.E * p.A;
     const long pair0 = gw * 16;
-    if (pair0 >= npairs) return;                                // whole wave out of range
+    // no early exit: every wavefront of the workgroup takes part in the weight staging barriers
     long pair = pair0 + j;
     const bool valid = pair < npairs;
     if (!valid) pair = npairs - 1;
@@ -149,9 +151,9 @@ __global__ __launch_bounds__(kSarlWaves * 64) void sarl_value_kernel(const SarlP
         for (int r = 0; r < 4; ++r)      // register r of lane group q carries feature 4q + r
             x[0][r] = q == 0 ? feat[r] : (q == 1 ? feat[4 + r] : (q == 2 ? feat[8 + r] : feat[12 + r]));
         f32x4 h1[T150];
-        dense<T13, T150, true>(x, h1, p.f.w_m1a, p.f.b_m1a, lane);
+        dense_staged<T13, T150, true, false>(x, nullptr, h1, p.f.w_m1a, p.f.b_m1a, S, lane);
         f32x4 h2[T100];
-        dense<T150, T100, true>(h1, h2, p.f.w_m1b, p.f.b_m1b, lane);
+        dense_staged<T150, T100, true, false>(h1, nullptr, h2, p.f.w_m1b, p.f.b_m1b, S, lane);
 #pragma unroll
         for (int t = 0; t < T100; ++t) {
             ws[(i * T100 + t) * 64 + lane] = make_float4(h2[t][0], h2[t][1], h2[t][2], h2[t][3]);
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(kSarlWaves * 64) void sarl_value_kernel(const SarlP
 #pragma unroll
         for (int r = 0; r < 4; ++r) gsum[t][r] = gsum[t][r] / fn;
     f32x4 gat[T100];
-    dense<T100, T100, false>(gsum, gat, p.f.w_atg, p.f.b_ata, lane);
+    dense_staged<T100, T100, false, false>(gsum, nullptr, gat, p.f.w_atg, p.f.b_ata, S, lane);
 
     // ---- pass 2: attention score, mlp2, pooling ----
     f32x4 pooled[T50];
@@ -189,20 +191,20 @@ __global__ __launch_bounds__(kSarlWaves * 64) void sarl_value_kernel(const SarlP
             h2[t] = (f32x4){v.x, v.y, v.z, v.w};
         }
         f32x4 a1[T100];
-        dense_acc<T100, T100, true>(h2, gat, a1, p.f.w_ata, lane);
+        dense_staged<T100, T100, true, true>(h2, gat, a1, p.f.w_ata, nullptr, S, lane);
         f32x4 a2[T100];
-        dense<T100, T100, true>(a1, a2, p.f.w_atb, p.f.b_atb, lane);
+        dense_staged<T100, T100, true, false>(a1, nullptr, a2, p.f.w_atb, p.f.b_atb, S, lane);
         f32x4 sc[T1];
-        dense<T100, T1, false>(a2, sc, p.f.w_atc, p.f.b_atc, lane);
+        dense_staged<T100, T1, false, false>(a2, nullptr, sc, p.f.w_atc, p.f.b_atc, S, lane);
         // score of pair j sits in lane j (q = 0), register 0; broadcast to the pair's four lanes
         const float s = __shfl(sc[0][0], j);
         const float es = (s != 0.0f) ? expf(s) : 0.0f;          // exp(s) * (s != 0), sarl.py:52
         if (p.attention && valid && q == 0) p.attention[pair * N + i] = es;   // normalised by the host view
         denom += es;
         f32x4 m1[T100];
-        dense<T100, T100, true>(h2, m1, p.f.w_m2a, p.f.b_m2a, lane);
+        dense_staged<T100, T100, true, false>(h2, nullptr, m1, p.f.w_m2a, p.f.b_m2a, S, lane);
         f32x4 m2[T50];
-        dense<T100, T50, false>(m1, m2, p.f.w_m2b, p.f.b_m2b, lane);
+        dense_staged<T100, T50, false, false>(m1, nullptr, m2, p.f.w_m2b, p.f.b_m2b, S, lane);
 #pragma unroll
         for (int t = 0; t < T50; ++t)
 #pragma unroll
@@ -221,13 +223,13 @@ __global__ __launch_bounds__(kSarlWaves * 64) void sarl_value_kernel(const SarlP
         for (int r = 0; r < 4; ++r) jin[T50][r] = q == 0 ? self6[r] : (q == 1 ? self6[4 + r] : 0.0f);
     }
     f32x4 v1[T150];
-    dense<T56, T150, true>(jin, v1, p.f.w_m3a, p.f.b_m3a, lane);
+    dense_staged<T56, T150, true, false>(jin, nullptr, v1, p.f.w_m3a, p.f.b_m3a, S, lane);
     f32x4 v2[T100];
-    dense<T150, T100, true>(v1, v2, p.f.w_m3b, p.f.b_m3b, lane);
+    dense_staged<T150, T100, true, false>(v1, nullptr, v2, p.f.w_m3b, p.f.b_m3b, S, lane);
     f32x4 v3[T100];
-    dense<T100, T100, true>(v2, v3, p.f.w_m3c, p.f.b_m3c, lane);
+    dense_staged<T100, T100, true, false>(v2, nullptr, v3, p.f.w_m3c, p.f.b_m3c, S, lane);
     f32x4 vo[T1];
-    dense<T100, T1, false>(v3, vo, p.f.w_m3d, p.f.b_m3d, lane);
+    dense_staged<T100, T1, false, false>(v3, nullptr, vo, p.f.w_m3d, p.f.b_m3d, S, lane);
     if (valid && q == 0) {
         // value = reward + gamma^(dt * v_pref) * V   (multi_human_rl.py:52, Python float arithmetic)
         p.values[pair] = reward + p.gamma_pow * (double)vo[0][0];

@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--sweep", type=str, default="65536,1048576,4194304", help="extra batch sizes for roofline_sweep")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the SARL / SGAN configurations")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
 
@@ -121,6 +122,90 @@ def roofline_entry(E, N, avg_ms, extra=None, given=False):
     if extra:
         d.update(extra)
     return d
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 MFMA (= fp32 vector peak)
+
+
+def _sarl_policy(device, dt):
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.policy.sarl import SARL
+    torch.manual_seed(0)                       # default-init weights: the reference ships no trained SARL model
+    pol = SARL()
+    pol.configure(configs.policy_config())
+    pol.kinematics = "holonomic"
+    pol.set_device(device)
+    pol.set_phase("test")
+    pol.time_step = dt
+    return pol
+
+
+def _timed(fn, iters):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn(); fn()
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def extra_configs(device):
+    """BASELINE configs[2] and [3], same batch shape, reported next to the headline workload."""
+    out = []
+    # ---- config 3: 4096 envs x 5 humans, SARL attention value-net robot ----
+    E, N = 4096, 5
+    env, _ = build_env(E, N, 0, device)
+    pol = _sarl_policy(device, env.time_step)
+
+    def step3():
+        a, _ = pol.predict_batch(env)
+        env.step(a)
+    ms_step = _timed(step3, 30)
+    ms_net = _timed(lambda: pol.predict_batch(env), 30)
+    flop = 81 * (N * 124100 + 67000) * E
+    out.append({"config": "4096 envs x 5 humans, SARL attention value-net robot (81-action look-ahead), ORCA humans",
+                "ms_per_step": round(ms_step, 4), "env_steps_per_sec": round(E / ms_step * 1e3, 1),
+                "roofline": {"bound": "mfma", "kernel": "mcn::sarl_value_kernel", "achieved": round(flop / ms_net / 1e9, 2),
+                             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop / ms_net / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
+                             "traffic": None, "algorithmic_flop_per_launch": flop, "avg_launch_us": round(ms_net * 1e3, 1),
+                             "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}})
+    del env
+    # ---- config 4: 4096 envs x 10 humans, model-based rollout with the SGAN predictor ----
+    gold = os.path.join(ROOT, "tests", "golden", "g6_sgan.npz")
+    if os.path.exists(gold):
+        from modelcrowdnav_amd import configs
+        from modelcrowdnav_amd.envs import VecModelCrowdSim
+        from modelcrowdnav_amd.envs.utils.robot import Robot
+        from modelcrowdnav_amd.envs import scenarios as S
+        from modelcrowdnav_amd.policy.world_model import VecSGANWorld, generator_from_arrays
+        N = 10
+        cfg = configs.env_config(**{"sim.human_num": N})
+        env = VecModelCrowdSim(E, device)
+        env.configure(cfg)
+        robot = Robot(cfg, "robot")
+        pol4 = _sarl_policy(device, env.time_step)
+        robot.set_policy(pol4)
+        env.set_robot(robot)
+        pool = S.scenario_pool(env.spec(), "test", range(500), N, "circle_crossing")
+        env.load_scenarios(pool[np.arange(E) % 500])
+        env.attach_rollout(gamma=0.9, pool=pool, case_stride=1, first_cases=(np.arange(E) + 1) % 500)
+        gen = generator_from_arrays(np.load(gold), "p", device)          # shipped sgan-p-models/zara1_8 weights
+        world = VecSGANWorld(gen, E, N, device, time_step=env.time_step, seed=0)
+        world.init_constant_velocity(env.hpos, env.hvel)
+        env.sim_world = world
+
+        def step4():
+            a, _ = pol4.predict_batch(env)
+            env.step(a)                      # asks sim_world (SGAN) for the humans' velocities
+        ms4 = _timed(step4, 20)
+        ms_sgan = _timed(lambda: world(env.hpos), 20)
+        out.append({"config": "4096 envs x 10 humans, model-based rollout: SGAN (pool-net, zara1_8) world model + SARL robot",
+                    "ms_per_step": round(ms4, 4), "env_steps_per_sec": round(E / ms4 * 1e3, 1),
+                    "sgan_step_ms": round(ms_sgan, 4)})
+    return out
 
 
 def cpu_baseline(N, seconds):
@@ -260,6 +345,10 @@ def main():
             del gv
             del env_s, a_s
         result["roofline_sweep"] = sweep
+
+    if rank == 0 and world == 1 and not args.no_extra:
+        torch.cuda.empty_cache()
+        result["extra_configs"] = extra_configs(device)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(N, args.cpu_seconds)

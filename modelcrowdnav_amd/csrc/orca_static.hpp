@@ -16,8 +16,9 @@
 
 namespace mcn {
 
-// 1-D LP on line NO (compile-time) against lines [0, NO), closest-point objective.
-template <int NO, int NL>
+// 1-D LP on line NO (compile-time) against lines [0, NO).  DIR = false: closest point to (optx,opty);
+// DIR = true: farthest point along the unit direction (optx,opty) (used by the 3-D LP).
+template <int NO, int NL, bool DIR = false>
 __device__ __forceinline__ bool lp1_s(const float4 (&L)[NL], float radius, float optx, float opty, float &rx, float &ry)
 {
     const float4 ln = L[NO];
@@ -45,14 +46,19 @@ __device__ __forceinline__ bool lp1_s(const float4 (&L)[NL], float radius, float
     // a failed lane keeps computing garbage that is discarded: once ok is false it stays false,
     // and the reference returns at the first failure without touching the result
     if (!ok) return false;
-    float t = dot2(ln.z, ln.w, optx - ln.x, opty - ln.y);
-    if (t < tl) t = tl; else if (t > tr) t = tr;
+    float t;
+    if constexpr (DIR) {
+        t = (dot2(optx, opty, ln.z, ln.w) > 0.0f) ? tr : tl;
+    } else {
+        t = dot2(ln.z, ln.w, optx - ln.x, opty - ln.y);
+        if (t < tl) t = tl; else if (t > tr) t = tr;
+    }
     rx = ln.x + t * ln.z;
     ry = ln.y + t * ln.w;
     return true;
 }
 
-template <int I, int NL>
+template <int I, int NL, bool DIR = false>
 struct Lp2Step {
     static __device__ __forceinline__ void run(const float4 (&L)[NL], int n, float radius, float optx, float opty,
                                                float &rx, float &ry, int &fail)
@@ -62,14 +68,66 @@ struct Lp2Step {
                 const float4 li = L[I];
                 if (det2(li.z, li.w, li.x - rx, li.y - ry) > 0.0f) {
                     float nx = rx, ny = ry;
-                    if (lp1_s<I, NL>(L, radius, optx, opty, nx, ny)) { rx = nx; ry = ny; }
+                    if (lp1_s<I, NL, DIR>(L, radius, optx, opty, nx, ny)) { rx = nx; ry = ny; }
                     else fail = I;
                 }
             }
-            Lp2Step<I + 1, NL>::run(L, n, radius, optx, opty, rx, ry, fail);
+            Lp2Step<I + 1, NL, DIR>::run(L, n, radius, optx, opty, rx, ry, fail);
         }
     }
 };
+
+// Register-resident 3-D LP (minimise the maximum penetration) for small line counts: step I projects lines
+// [0, I) onto line I, runs the direction-optimising 2-D LP on them and updates the penetration bound.
+template <int I, int NL>
+struct Lp3Step {
+    static __device__ __forceinline__ void run(const float4 (&L)[NL], int n, int begin, float radius, float &rx, float &ry,
+                                               float &dist)
+    {
+        if constexpr (I < NL) {
+            if (I >= begin && I < n) {
+                const float4 li = L[I];
+                if (det2(li.z, li.w, li.x - rx, li.y - ry) > dist) {
+                    constexpr int NP = I > 0 ? I : 1;
+                    float4 P[NP];
+                    int m = 0;
+#pragma unroll
+                    for (int jj = 0; jj < I; ++jj) {
+                        const float4 lj = L[jj];
+                        const float dt = det2(li.z, li.w, lj.z, lj.w);
+                        float qx, qy;
+                        bool skip = false;
+                        if (fabsf(dt) <= kRvoEps) {
+                            if (dot2(li.z, li.w, lj.z, lj.w) > 0.0f) skip = true;
+                            qx = 0.5f * (li.x + lj.x); qy = 0.5f * (li.y + lj.y);
+                        } else {
+                            const float sc = det2(lj.z, lj.w, li.x - lj.x, li.y - lj.y) / dt;
+                            qx = li.x + sc * li.z; qy = li.y + sc * li.w;
+                        }
+                        const float ddx = lj.z - li.z, ddy = lj.w - li.w;
+                        const float inv = 1.0f / sqrtf(dot2(ddx, ddy, ddx, ddy));
+                        const float4 q = make_float4(qx, qy, ddx * inv, ddy * inv);
+                        // compact the kept lines to the front (m is the running count): static slots via selects
+#pragma unroll
+                        for (int sl = 0; sl < NP; ++sl)
+                            if (!skip && sl == m) P[sl] = q;
+                        m += skip ? 0 : 1;
+                    }
+                    const float kx = rx, ky = ry;
+                    const float ox = -li.w, oy = li.z;
+                    rx = radius * ox; ry = radius * oy;
+                    int fail = m;
+                    if constexpr (I > 0) Lp2Step<0, NP, true>::run(P, m, radius, ox, oy, rx, ry, fail);
+                    if (fail < m) { rx = kx; ry = ky; }
+                    dist = det2(li.z, li.w, li.x - rx, li.y - ry);
+                }
+            }
+            Lp3Step<I + 1, NL>::run(L, n, begin, radius, rx, ry, dist);
+        }
+    }
+};
+
+constexpr int kLp3StaticMax = 5;      // above this the unrolled code grows as NL^3: use the generic solver
 
 // NC candidates in insertion order -> new velocity.  cpv[c] = (px,py,vx,vy), crad[c] = radius.
 template <int NC>
@@ -162,7 +220,12 @@ __device__ __forceinline__ void orca_solve_static(float4 (&cpv)[NC > 0 ? NC : 1]
     int fail = nl;
     Lp2Step<0, NL>::run(L, nl, max_speed, prefx, prefy, rx, ry, fail);
 
-    if (fail < nl) {
+    if constexpr (NL <= kLp3StaticMax) {
+        if (fail < nl) {
+            float dist = 0.0f;
+            Lp3Step<0, NL>::run(L, nl, fail, max_speed, rx, ry, dist);
+        }
+    } else if (fail < nl) {
         // dense-crowd fallback: minimise the maximum penetration (generic solver, private memory)
         float4 buf[NL];
 #pragma unroll

@@ -111,9 +111,15 @@ def time_kernel_events(env, acts, n, given_v=None, reps=3):
     return float(np.mean(per)), float(np.min(per))
 
 
+def pairwise_bytes_per_env_step(N):
+    """Given-velocity (ModelCrowdSim.step / pairwise-only) variant: it needs no goals and no v_pref.
+    read  robot px,py,gx,gy,r + action 2 + t 1 = 8, humans px,py,vx,vy,r + given vx,vy = 7N;
+    write robot px,py,vx,vy + t = 5, humans px,py,vx,vy = 4N, reward + dmin = 2; + 6 B masks/counters."""
+    return (15 + 11 * N) * 8 + 6
+
+
 def roofline_entry(E, N, avg_ms, extra=None, given=False):
-    # given-velocity (ModelCrowdSim / pairwise-only) mode also reads the [E,N,2] velocity input
-    by = (algorithmic_bytes_per_env_step(N) + (16 * N if given else 0)) * E
+    by = (pairwise_bytes_per_env_step(N) if given else algorithmic_bytes_per_env_step(N)) * E
     ach = by / (avg_ms * 1e-3) / 1e9
     d = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,

@@ -12,12 +12,14 @@
  *
  * Buffer conventions (E environments, N humans, row-major, env-major):
  *   double2-packed arrays are [E*N][2] or [E][2] doubles, 16-byte aligned.
- *   hpos  (px,py)   hvel (vx,vy)   hgoal (gx,gy)   hattr (radius, v_pref)     [E*N][2]
- *   rpos  (px,py)   rvel (vx,vy)   rgoal (gx,gy)   rattr (radius, v_pref)     [E][2]
+ *   hpos  (px,py)   hvel (vx,vy)   hgoal (gx,gy)                              [E*N][2]
+ *   hrad, hvpref (radius, v_pref: separate so kernels that need only the radius stream only it)  [E*N]
+ *   rpos  (px,py)   rvel (vx,vy)   rgoal (gx,gy)                              [E][2]
+ *   rrad, rvpref                                                              [E]
  *   rtheta, gtime                                                             [E]
  * The observation the reference returns from step()/reset() -- a list of
  * ObservableState(px,py,vx,vy,radius), crowd_sim/envs/utils/state.py:27-43 -- is
- * (hpos, hvel, hattr[:,0]) and is therefore never copied.
+ * (hpos, hvel, hrad) and is therefore never copied.
  */
 #ifndef MCN_H_
 #define MCN_H_
@@ -64,8 +66,10 @@ typedef struct mcn_env_cfg {
 
 /* Device state of E environments (all device pointers, caller-owned). */
 typedef struct mcn_env_state {
-    double *hpos, *hvel, *hgoal, *hattr;       /* [E*N][2] */
-    double *rpos, *rvel, *rgoal, *rattr;       /* [E][2]   */
+    double *hpos, *hvel, *hgoal;               /* [E*N][2] */
+    double *hrad, *hvpref;                     /* [E*N]    */
+    double *rpos, *rvel, *rgoal;               /* [E][2]   */
+    double *rrad, *rvpref;                     /* [E]      */
     double *rtheta;                            /* [E]      */
     double *gtime;                             /* [E]  CrowdSim.global_time */
     double *human_times;                       /* [E*N] or NULL */
@@ -103,7 +107,8 @@ typedef struct mcn_rollout {
     int32_t *danger_count;     /* [E] steps whose info was Danger, or NULL */
     double  *danger_dist_sum;  /* [E] sum of their min_dist, or NULL */
     /* auto-reset from a pool of host-generated scenarios (bit-exact CrowdSim.reset output) */
-    const double *pool_hpos, *pool_hgoal, *pool_hattr;   /* [P*N][2] */
+    const double *pool_hpos, *pool_hgoal;                /* [P*N][2] */
+    const double *pool_hrad, *pool_hvpref;               /* [P*N]    */
     const double *pool_hvel;                             /* [P*N][2] or NULL (zeros) */
     int32_t pool_size;
     int32_t *next_case;        /* [E] index into the pool used at the next reset; advanced by case_stride mod pool_size */

@@ -32,7 +32,7 @@ class EnvCfg(C.Structure):
 
 
 class EnvState(C.Structure):
-    _fields_ = [(k, _vp) for k in ("hpos", "hvel", "hgoal", "hattr", "rpos", "rvel", "rgoal", "rattr",
+    _fields_ = [(k, _vp) for k in ("hpos", "hvel", "hgoal", "hrad", "hvpref", "rpos", "rvel", "rgoal", "rrad", "rvpref",
                                    "rtheta", "gtime", "human_times")]
 
 
@@ -46,7 +46,7 @@ class Rollout(C.Structure):
         ("ep_return", _vp), ("ep_steps", _vp),
         ("fin_return", _vp), ("fin_time", _vp), ("fin_info", _vp), ("fin_count", _vp), ("fin_slots", _i),
         ("danger_count", _vp), ("danger_dist_sum", _vp),
-        ("pool_hpos", _vp), ("pool_hgoal", _vp), ("pool_hattr", _vp), ("pool_hvel", _vp),
+        ("pool_hpos", _vp), ("pool_hgoal", _vp), ("pool_hrad", _vp), ("pool_hvpref", _vp), ("pool_hvel", _vp),
         ("pool_size", _i), ("next_case", _vp), ("case_stride", _i),
         ("robot_start", _d * 2), ("robot_goal", _d * 2), ("robot_theta0", _d),
     ]

@@ -111,20 +111,30 @@ void env_step_kernel(const StepParams p)
         pos  = reinterpret_cast<const double2 *>(p.st.hpos)[a];
         vel  = reinterpret_cast<const double2 *>(p.st.hvel)[a];
         if constexpr (MODE != MCN_HUMANS_GIVEN) goal = reinterpret_cast<const double2 *>(p.st.hgoal)[a];
-        attr = reinterpret_cast<const double2 *>(p.st.hattr)[a];
+        attr.x = p.st.hrad[a];
+        if constexpr (MODE != MCN_HUMANS_GIVEN) attr.y = p.st.hvpref[a];
     }
     double2 rpos = make_double2(0, 0), rvel = rpos, rgoal = rpos, rattr = rpos, act = rpos;
     double rtheta = 0, gtime = 0;
-    int next_case = 0;
+    int next_case = 0, ep_t = 0, ep_k = 0;
+    double ep_ret = 0, ep_disc = 0;
     if (leader) {
         rpos  = reinterpret_cast<const double2 *>(p.st.rpos)[e];
         rvel  = reinterpret_cast<const double2 *>(p.st.rvel)[e];
         rgoal = reinterpret_cast<const double2 *>(p.st.rgoal)[e];
-        rattr = reinterpret_cast<const double2 *>(p.st.rattr)[e];
+        rattr.x = p.st.rrad[e];
         act   = reinterpret_cast<const double2 *>(p.actions)[e];
         gtime = p.st.gtime[e];
         if (c.robot_kinematics == MCN_KIN_UNICYCLE) rtheta = p.st.rtheta[e];
         if (p.has_roll && p.roll.next_case) next_case = p.roll.next_case[e];
+        // rollout bookkeeping operands are fetched now, so their latency hides under the ORCA solve instead of
+        // forming a dependent load chain (steps -> discount) at the very end of the kernel
+        if (p.has_roll && p.roll.ep_return) {
+            ep_t = p.roll.ep_steps[e];
+            ep_ret = p.roll.ep_return[e];
+            ep_disc = p.roll.disc_table[ep_t < p.roll.disc_len ? ep_t : p.roll.disc_len - 1];
+            ep_k = p.roll.fin_count ? p.roll.fin_count[e] : 0;
+        }
     }
     // effective robot velocity for the swept test (crowd_sim.py:350-355)
     double2 eff = act;
@@ -291,7 +301,8 @@ void env_step_kernel(const StepParams p)
             const long pa = (long)case_g * N + h;
             reinterpret_cast<double2 *>(p.st.hpos)[a]  = reinterpret_cast<const double2 *>(p.roll.pool_hpos)[pa];
             reinterpret_cast<double2 *>(p.st.hgoal)[a] = reinterpret_cast<const double2 *>(p.roll.pool_hgoal)[pa];
-            reinterpret_cast<double2 *>(p.st.hattr)[a] = reinterpret_cast<const double2 *>(p.roll.pool_hattr)[pa];
+            p.st.hrad[a] = p.roll.pool_hrad[pa];
+            p.st.hvpref[a] = p.roll.pool_hvpref[pa];
             reinterpret_cast<double2 *>(p.st.hvel)[a]  = p.roll.pool_hvel
                 ? reinterpret_cast<const double2 *>(p.roll.pool_hvel)[pa] : make_double2(0, 0);
             if (p.st.human_times) p.st.human_times[a] = 0;
@@ -314,10 +325,10 @@ void env_step_kernel(const StepParams p)
                 if (r.danger_dist_sum) r.danger_dist_sum[e] += dmin;
             }
             if (r.ep_return) {
-                const int t = r.ep_steps[e];
-                const double ret = r.ep_return[e] + r.disc_table[t < r.disc_len ? t : r.disc_len - 1] * rew;
+                const int t = ep_t;
+                const double ret = ep_ret + ep_disc * rew;
                 if (dn) {
-                    const int k = r.fin_count ? r.fin_count[e] : 0;
+                    const int k = ep_k;
                     // fin_slots == 1: keep the latest episode; otherwise keep the first fin_slots episodes
                     const bool keep = (r.fin_slots == 1) || (k < r.fin_slots);
                     const long rec = (long)(r.fin_slots == 1 ? 0 : k) * p.E + e;

@@ -32,8 +32,8 @@ int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *
 {
     if (!cfg || !st || !out || !actions) return MCN_EINVAL;
     if (E <= 0 || N <= 0 || N > MCN_MAX_HUMANS) return MCN_EINVAL;
-    if (!st->hpos || !st->hvel || !st->hgoal || !st->hattr || !st->rpos || !st->rvel || !st->rgoal ||
-        !st->rattr || !st->gtime) return MCN_EINVAL;
+    if (!st->hpos || !st->hvel || !st->hgoal || !st->hrad || !st->hvpref || !st->rpos || !st->rvel || !st->rgoal ||
+        !st->rrad || !st->gtime) return MCN_EINVAL;
     if (cfg->robot_kinematics == MCN_KIN_UNICYCLE && !st->rtheta) return MCN_EINVAL;
     if (!out->reward || !out->dmin || !out->done || !out->info || !out->hh_count) return MCN_EINVAL;
     if (!update && (!out->nobs_pos || !out->nobs_vel)) return MCN_EINVAL;
@@ -44,7 +44,7 @@ int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *
     if (roll) {
         if (roll->ep_return && (!roll->ep_steps || !roll->disc_table || roll->disc_len <= 0)) return MCN_EINVAL;
         if (roll->ep_return && roll->fin_slots < 1) return MCN_EINVAL;
-        if (roll->pool_hpos && (!roll->pool_hgoal || !roll->pool_hattr || roll->pool_size <= 0)) return MCN_EINVAL;
+        if (roll->pool_hpos && (!roll->pool_hgoal || !roll->pool_hrad || !roll->pool_hvpref || roll->pool_size <= 0)) return MCN_EINVAL;
     }
     mcn::StepParams p;
     memset(&p, 0, sizeof(p));
@@ -113,7 +113,7 @@ int mcn_sarl_lookahead(const mcn_sarl_net *net, const mcn_env_state *st, const d
     if (!net || !st || !actions || !workspace || !values) return MCN_EINVAL;
     if (E <= 0 || N <= 0 || N > MCN_MAX_HUMANS || A <= 0) return MCN_EINVAL;
     if (best && !best_val) return MCN_EINVAL;
-    if (!st->hpos || !st->hvel || !st->hattr || !st->rpos || !st->rgoal || !st->rattr) return MCN_EINVAL;
+    if (!st->hpos || !st->hvel || !st->hrad || !st->rpos || !st->rgoal || !st->rrad || !st->rvpref) return MCN_EINVAL;
     if (kinematics == MCN_KIN_UNICYCLE && !st->rtheta) return MCN_EINVAL;
     const float *const *fp = reinterpret_cast<const float *const *>(net);
     for (size_t k = 0; k < sizeof(mcn_sarl_net) / sizeof(float *); ++k)

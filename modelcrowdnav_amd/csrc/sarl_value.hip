@@ -60,8 +60,8 @@ struct SarlFrags {
 struct SarlParams {
     SarlFrags f;
     // state (same buffers as mcn_env_state)
-    const double *rpos, *rvel, *rgoal, *rattr, *rtheta;   // [E][2] / [E]
-    const double *hpos, *hvel, *hattr;                    // [E*N][2]
+    const double *rpos, *rvel, *rgoal, *rrad, *rvpref, *rtheta;   // [E][2] / [E]
+    const double *hpos, *hvel, *hrad;                             // [E*N][2] / [E*N]
     const double *actions;                                // [A][2]
     float4 *workspace;                                    // [waves][N][T100][64] float4
     double *values;                                       // [E*A]
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, 2) void sarl_value_kernel(const Sa
     // ---- robot after the candidate action (cadrl.py:104-129), float64 like the reference ----
     const double2 rp = reinterpret_cast<const double2 *>(p.rpos)[e];
     const double2 rg = reinterpret_cast<const double2 *>(p.rgoal)[e];
-    const double2 ra = reinterpret_cast<const double2 *>(p.rattr)[e];      // radius, v_pref
+    const double2 ra = make_double2(p.rrad[e], p.rvpref[e]);               // radius, v_pref
     const double2 ac = reinterpret_cast<const double2 *>(p.actions)[a];
     double npx, npy, nvx, nvy, nth;
     if (p.kinematics == MCN_KIN_UNICYCLE) {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, 2) void sarl_value_kernel(const Sa
         const long ha = (long)e * N + i;
         const double2 hp = reinterpret_cast<const double2 *>(p.hpos)[ha];
         const double2 hv = reinterpret_cast<const double2 *>(p.hvel)[ha];
-        const double hr = p.hattr[2 * ha];
+        const double hr = p.hrad[ha];
         const double qx = hp.x + hv.x * dt, qy = hp.y + hv.y * dt;      // constant-velocity propagate
         const double d = norm2d(npx - qx, npy - qy) - ra.x - hr;        // multi_human_rl.py:70
         dmin = fmin(dmin, d);
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, 2) void sarl_value_kernel(const Sa
 // wins), one wavefront per env.  Also reports reach_destination (policy.py:43-49), for which the reference
 // returns the zero action without evaluating anything.
 __global__ __launch_bounds__(64) void sarl_argmax_kernel(const double *__restrict__ values, const double *rpos,
-                                                       const double *rgoal, const double *rattr, int E, int A,
+                                                       const double *rgoal, const double *rrad, int E, int A,
                                                        int32_t *__restrict__ best, double *__restrict__ best_val)
 {
     const int e = blockIdx.x;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64) void sarl_argmax_kernel(const double *__restric
         const double2 rp = reinterpret_cast<const double2 *>(rpos)[e];
         const double2 rg = reinterpret_cast<const double2 *>(rgoal)[e];
         // numpy norm((py - gy, px - gx)): dot = fma(x1, x1, x0 * x0) with x0 = py-gy, x1 = px-gx
-        const bool reached = norm2d(rp.y - rg.y, rp.x - rg.x) < rattr[2 * e];
+        const bool reached = norm2d(rp.y - rg.y, rp.x - rg.x) < rrad[e];
         best[e] = reached ? -1 : bi;
         best_val[e] = bv;
     }
@@ -276,7 +276,7 @@ int launch_sarl(const SarlParams &p, int32_t *best, double *best_val, hipStream_
     const int blocks = (int)((waves + kSarlWaves - 1) / kSarlWaves);
     hipLaunchKernelGGL(sarl_value_kernel, dim3(blocks), dim3(kSarlWaves * 64), 0, stream, p);
     if (best) {
-        hipLaunchKernelGGL(sarl_argmax_kernel, dim3(p.E), dim3(64), 0, stream, p.values, p.rpos, p.rgoal, p.rattr,
+        hipLaunchKernelGGL(sarl_argmax_kernel, dim3(p.E), dim3(64), 0, stream, p.values, p.rpos, p.rgoal, p.rrad,
                            p.E, p.A, best, best_val);
     }
     return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
@@ -291,8 +291,8 @@ int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double
     const float4 **dst = reinterpret_cast<const float4 **>(&p.f);
     static_assert(sizeof(SarlFrags) == sizeof(mcn_sarl_net), "fragment tables must mirror the C struct");
     for (size_t k = 0; k < sizeof(mcn_sarl_net) / sizeof(float *); ++k) dst[k] = src[k];
-    p.rpos = st->rpos; p.rvel = st->rvel; p.rgoal = st->rgoal; p.rattr = st->rattr; p.rtheta = st->rtheta;
-    p.hpos = st->hpos; p.hvel = st->hvel; p.hattr = st->hattr;
+    p.rpos = st->rpos; p.rvel = st->rvel; p.rgoal = st->rgoal; p.rrad = st->rrad; p.rvpref = st->rvpref; p.rtheta = st->rtheta;
+    p.hpos = st->hpos; p.hvel = st->hvel; p.hrad = st->hrad;
     p.actions = actions; p.workspace = reinterpret_cast<float4 *>(workspace);
     p.values = values; p.attention = attention;
     p.E = E; p.N = N; p.A = A; p.kinematics = kinematics; p.dt = dt; p.gamma_pow = gamma_pow;

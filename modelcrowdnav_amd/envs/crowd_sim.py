@@ -27,7 +27,7 @@ _UINT32_MAX = int(np.iinfo(np.uint32).max)
 class ObsBatch(object):
     """Observation of a batch: views of the state arrays (never copied by step()).
 
-    pos, vel: [E,N,2] float64; radius: [E,N] float64 (a strided view of hattr).
+    pos, vel: [E,N,2] float64; radius: [E,N] float64.
     `tensor()` materialises the reference's per-human 5-tuple layout [E,N,5]
     (px,py,vx,vy,radius: crowd_sim/envs/utils/state.py:27-33) when a caller wants it.
     """
@@ -114,8 +114,10 @@ class VecCrowdSim(object):
     def _allocate(self, N):
         E, dev, f64 = self.num_envs, self.device, torch.float64
         z = lambda *shape, dtype=f64: torch.zeros(*shape, dtype=dtype, device=dev)
-        self.hpos, self.hvel, self.hgoal, self.hattr = z(E, N, 2), z(E, N, 2), z(E, N, 2), z(E, N, 2)
-        self.rpos, self.rvel, self.rgoal, self.rattr = z(E, 2), z(E, 2), z(E, 2), z(E, 2)
+        self.hpos, self.hvel, self.hgoal = z(E, N, 2), z(E, N, 2), z(E, N, 2)
+        self.hrad, self.hvpref = z(E, N), z(E, N)
+        self.rpos, self.rvel, self.rgoal = z(E, 2), z(E, 2), z(E, 2)
+        self.rrad, self.rvpref = z(E), z(E)
         self.rtheta, self.gtime = z(E), z(E)
         self.human_times = z(E, N)
         self.reward, self.dmin = z(E), z(E)
@@ -124,9 +126,9 @@ class VecCrowdSim(object):
         self.human_act = z(E, N, 2)
         self.nobs_pos, self.nobs_vel = z(E, N, 2), z(E, N, 2)
         self._alloc_N = N
-        self._st = _hip.EnvState(*[_hip.ptr(t) for t in (self.hpos, self.hvel, self.hgoal, self.hattr, self.rpos,
-                                                         self.rvel, self.rgoal, self.rattr, self.rtheta, self.gtime,
-                                                         self.human_times)])
+        self._st = _hip.EnvState(*[_hip.ptr(t) for t in (self.hpos, self.hvel, self.hgoal, self.hrad, self.hvpref,
+                                                         self.rpos, self.rvel, self.rgoal, self.rrad, self.rvpref,
+                                                         self.rtheta, self.gtime, self.human_times)])
         self._out = _hip.EnvOut(*[_hip.ptr(t) for t in (self.reward, self.dmin, self.done, self.info, self.hh_count,
                                                         self.human_act, self.nobs_pos, self.nobs_vel)])
         self._out_lean = _hip.EnvOut(*[_hip.ptr(t) for t in (self.reward, self.dmin, self.done, self.info,
@@ -159,15 +161,16 @@ class VecCrowdSim(object):
         self.hpos.copy_(up(scen[:, :, [S.PX, S.PY]]))
         self.hgoal.copy_(up(scen[:, :, [S.GX, S.GY]]))
         self.hvel.copy_(up(scen[:, :, [S.VX, S.VY]]))
-        self.hattr.copy_(up(scen[:, :, [S.RAD, S.VPREF]]))
+        self.hrad.copy_(up(scen[:, :, S.RAD]))
+        self.hvpref.copy_(up(scen[:, :, S.VPREF]))
         if robot_rows is None:
             robot_rows = np.tile(self.spec().robot_row(), (E, 1))      # crowd_sim.py:284
         robot_rows = np.asarray(robot_rows, np.float64)
         self.rpos.copy_(up(robot_rows[:, [S.PX, S.PY]]))
         self.rgoal.copy_(up(robot_rows[:, [S.GX, S.GY]]))
         self.rvel.copy_(up(robot_rows[:, [S.VX, S.VY]]))
-        ra = np.stack([robot_rows[:, S.RAD], np.full(E, float(self.robot.v_pref))], 1)
-        self.rattr.copy_(up(ra))
+        self.rrad.copy_(up(robot_rows[:, S.RAD]))
+        self.rvpref.fill_(float(self.robot.v_pref))
         self.rtheta.copy_(up(robot_rows[:, S.TH]))
         self.gtime.zero_()
         self.human_times.zero_()
@@ -200,7 +203,7 @@ class VecCrowdSim(object):
         return self.observation()
 
     def observation(self):
-        return ObsBatch(self.hpos, self.hvel, self.hattr[..., 0])
+        return ObsBatch(self.hpos, self.hvel, self.hrad)
 
     def step(self, actions, update=True, given_v=None):
         """crowd_sim.py:331-434 for every env: one mcn_env_step launch, no host sync.
@@ -228,7 +231,7 @@ class VecCrowdSim(object):
         if update:
             ob = self.observation()
         else:
-            ob = ObsBatch(self.nobs_pos, self.nobs_vel, self.hattr[..., 0])
+            ob = ObsBatch(self.nobs_pos, self.nobs_vel, self.hrad)
         return ob, self.reward, self.done, self.info
 
     def onestep_lookahead(self, actions):
@@ -265,11 +268,13 @@ class VecCrowdSim(object):
                 raise ValueError("pool N %d != env N %d" % (N, self._alloc_N))
             up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
             t["pool_hpos"] = up(pool[:, :, [S.PX, S.PY]]); t["pool_hgoal"] = up(pool[:, :, [S.GX, S.GY]])
-            t["pool_hattr"] = up(pool[:, :, [S.RAD, S.VPREF]]); t["pool_hvel"] = up(pool[:, :, [S.VX, S.VY]])
+            t["pool_hrad"] = up(pool[:, :, S.RAD]); t["pool_hvpref"] = up(pool[:, :, S.VPREF])
+            t["pool_hvel"] = up(pool[:, :, [S.VX, S.VY]])
             nc = np.arange(E) % P if first_cases is None else np.asarray(first_cases) % P
             t["next_case"] = torch.from_numpy(nc.astype(np.int32)).to(dev)
             r.pool_hpos, r.pool_hgoal = _hip.ptr(t["pool_hpos"]), _hip.ptr(t["pool_hgoal"])
-            r.pool_hattr, r.pool_hvel = _hip.ptr(t["pool_hattr"]), _hip.ptr(t["pool_hvel"])
+            r.pool_hrad, r.pool_hvpref = _hip.ptr(t["pool_hrad"]), _hip.ptr(t["pool_hvpref"])
+            r.pool_hvel = _hip.ptr(t["pool_hvel"])
             r.pool_size, r.next_case, r.case_stride = P, _hip.ptr(t["next_case"]), int(case_stride)
             rr = self.spec().robot_row()
             r.robot_start[0], r.robot_start[1] = rr[S.PX], rr[S.PY]
@@ -397,9 +402,10 @@ class CrowdSim(object):
         v.hpos.copy_(t([[h.px, h.py] for h in hs]).view(1, -1, 2))
         v.hvel.copy_(t([[h.vx, h.vy] for h in hs]).view(1, -1, 2))
         v.hgoal.copy_(t([[h.gx, h.gy] for h in hs]).view(1, -1, 2))
-        v.hattr.copy_(t([[h.radius, h.v_pref] for h in hs]).view(1, -1, 2))
+        v.hrad.copy_(t([h.radius for h in hs]).view(1, -1))
+        v.hvpref.copy_(t([h.v_pref for h in hs]).view(1, -1))
         v.rpos.copy_(t([[r.px, r.py]])); v.rvel.copy_(t([[r.vx, r.vy]]))
-        v.rgoal.copy_(t([[r.gx, r.gy]])); v.rattr.copy_(t([[r.radius, r.v_pref]]))
+        v.rgoal.copy_(t([[r.gx, r.gy]])); v.rrad.copy_(t([r.radius])); v.rvpref.copy_(t([r.v_pref]))
         v.rtheta.copy_(t([r.theta])); v.gtime.copy_(t([self.global_time]))
         if len(self.human_times) == len(hs):
             v.human_times.copy_(t([self.human_times]))

@@ -52,14 +52,14 @@ class VecModelCrowdSim(VecCrowdSim):
         self.human_num = N
         self.hpos.copy_(hpos); self.hvel.copy_(hvel)
         self.hgoal.zero_()
-        self.hattr[..., 0].copy_(hradius); self.hattr[..., 1].fill_(self._human_v_pref)
+        self.hrad.copy_(hradius); self.hvpref.fill_(self._human_v_pref)
         rr = self.spec().robot_row()
         self.rpos.copy_(torch.tensor([rr[S.PX], rr[S.PY]], dtype=torch.float64, device=self.device).expand(E, 2)
                         if robot_pos is None else robot_pos)
         self.rgoal.copy_(torch.tensor([rr[S.GX], rr[S.GY]], dtype=torch.float64, device=self.device).expand(E, 2)
                          if robot_goal is None else robot_goal)
         self.rvel.zero_(); self.rtheta.fill_(np.pi / 2); self.gtime.zero_()
-        self.rattr[:, 0].fill_(float(self.robot.radius)); self.rattr[:, 1].fill_(float(self.robot.v_pref))
+        self.rrad.fill_(float(self.robot.radius)); self.rvpref.fill_(float(self.robot.v_pref))
 
 
 class ModelCrowdSim(CrowdSim):

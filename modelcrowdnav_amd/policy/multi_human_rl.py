@@ -92,8 +92,8 @@ class MultiHumanRL(CADRL):
             f64 = torch.float64
             t = lambda rows: torch.tensor(rows, dtype=f64, device=dev)
             bufs = dict(hpos=t([[h.px, h.py] for h in humans]), hvel=t([[h.vx, h.vy] for h in humans]),
-                        hattr=t([[h.radius, 0.0] for h in humans]), rpos=t([[me.px, me.py]]),
-                        rvel=t([[me.vx, me.vy]]), rgoal=t([[me.gx, me.gy]]), rattr=t([[me.radius, me.v_pref]]),
+                        hrad=t([h.radius for h in humans]), rpos=t([[me.px, me.py]]),
+                        rvel=t([[me.vx, me.vy]]), rgoal=t([[me.gx, me.gy]]), rrad=t([me.radius]), rvpref=t([me.v_pref]),
                         rtheta=t([me.theta]))
             st = _hip.EnvState()
             for k, v in bufs.items():

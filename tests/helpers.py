@@ -59,10 +59,10 @@ def upload(env, st):
     dev = env.device
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     env.hpos.copy_(t(np.stack([st.hpx, st.hpy], -1))); env.hvel.copy_(t(np.stack([st.hvx, st.hvy], -1)))
-    env.hgoal.copy_(t(np.stack([st.hgx, st.hgy], -1))); env.hattr.copy_(t(np.stack([st.hr, st.hvpref], -1)))
+    env.hgoal.copy_(t(np.stack([st.hgx, st.hgy], -1))); env.hrad.copy_(t(st.hr)); env.hvpref.copy_(t(st.hvpref))
     env.rpos.copy_(t(np.stack([st.rpx, st.rpy], -1))); env.rvel.copy_(t(np.stack([st.rvx, st.rvy], -1)))
     env.rgoal.copy_(t(np.stack([st.rgx, st.rgy], -1)))
-    env.rattr.copy_(t(np.stack([st.rr, np.ones_like(st.rr)], -1)))
+    env.rrad.copy_(t(st.rr)); env.rvpref.fill_(1.0)
     env.gtime.copy_(t(st.gtime)); env.human_times.copy_(t(st.human_times))
     env.human_num = st.N
 
@@ -70,12 +70,12 @@ def upload(env, st):
 def download(env):
     st = cport.EnvState(env.num_envs, env._alloc_N)
     c = lambda x: x.detach().cpu().numpy()
-    hp, hv, hg, ha = c(env.hpos), c(env.hvel), c(env.hgoal), c(env.hattr)
+    hp, hv, hg = c(env.hpos), c(env.hvel), c(env.hgoal)
     st.hpx[:], st.hpy[:], st.hvx[:], st.hvy[:] = hp[..., 0], hp[..., 1], hv[..., 0], hv[..., 1]
-    st.hgx[:], st.hgy[:], st.hr[:], st.hvpref[:] = hg[..., 0], hg[..., 1], ha[..., 0], ha[..., 1]
-    rp, rv, rg, ra = c(env.rpos), c(env.rvel), c(env.rgoal), c(env.rattr)
+    st.hgx[:], st.hgy[:], st.hr[:], st.hvpref[:] = hg[..., 0], hg[..., 1], c(env.hrad), c(env.hvpref)
+    rp, rv, rg = c(env.rpos), c(env.rvel), c(env.rgoal)
     st.rpx[:], st.rpy[:], st.rvx[:], st.rvy[:] = rp[:, 0], rp[:, 1], rv[:, 0], rv[:, 1]
-    st.rgx[:], st.rgy[:], st.rr[:] = rg[:, 0], rg[:, 1], ra[:, 0]
+    st.rgx[:], st.rgy[:], st.rr[:] = rg[:, 0], rg[:, 1], c(env.rrad)
     st.gtime[:] = c(env.gtime); st.human_times[:] = c(env.human_times)
     return st
 

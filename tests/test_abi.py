@@ -27,11 +27,11 @@ def test_struct_sizes_match_header():
     """ctypes mirrors must have the C layout (all members naturally aligned, no packing surprises)."""
     from modelcrowdnav_amd import _hip
     assert ctypes.sizeof(_hip.EnvCfg) == 7 * 8 + 2 * 4 + 6 * 4
-    assert ctypes.sizeof(_hip.EnvState) == 11 * 8
+    assert ctypes.sizeof(_hip.EnvState) == 13 * 8
     assert ctypes.sizeof(_hip.EnvOut) == 8 * 8
     r = _hip.Rollout
     assert r.disc_len.offset == 8 and r.ep_return.offset == 16 and r.fin_slots.offset == 64
-    assert r.danger_count.offset == 72 and r.pool_hpos.offset == 88 and r.pool_size.offset == 120
+    assert r.danger_count.offset == 72 and r.pool_hpos.offset == 88 and r.pool_size.offset == 128
     assert r.robot_start.offset % 8 == 0
 
 

@@ -49,7 +49,7 @@ def main():
             for rep in range(3):
                 s.record(); graph.replay(); e.record(); torch.cuda.synchronize()
                 best = min(best, s.elapsed_time(e) / a.iters)
-            nb = bench.algorithmic_bytes_per_env_step(N) + (16 * N if mode == "given" else 0)
+            nb = bench.pairwise_bytes_per_env_step(N) if mode == "given" else bench.algorithmic_bytes_per_env_step(N)
             print("N=%d E=%8d mode=%-5s  %9.2f us/launch  %8.1f M env-steps/s  %7.1f GB/s (%.1f%% of 8 TB/s)" % (
                 N, E, mode, best * 1e3, E / best / 1e3, nb * E / best / 1e6, nb * E / best / 1e6 / 80.0))
         del env

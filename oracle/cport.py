@@ -25,12 +25,13 @@ class Cfg(C.Structure):
         ("orca_safety_space", C.c_double),
         ("orca_neighbor_dist", C.c_float), ("orca_max_neighbors", C.c_int),
         ("orca_time_horizon", C.c_float), ("orca_max_speed", C.c_float),
+        ("robot_unicycle", C.c_int),
     ]
 
 
 def default_cfg(**kw):
     """env.config:1-13,33 + orca.py:60-66 defaults."""
-    c = Cfg(0.25, 25.0, 1.0, -0.25, 0.2, 0.5, 0, HUMANS_ORCA, 1, 1, 0.0, 10.0, 10, 5.0, 1.0)
+    c = Cfg(0.25, 25.0, 1.0, -0.25, 0.2, 0.5, 0, HUMANS_ORCA, 1, 1, 0.0, 10.0, 10, 5.0, 1.0, 0)
     for k, v in kw.items():
         setattr(c, k, v)
     return c
@@ -114,11 +115,12 @@ class EnvState:
         for k in self.FIELDS_R:
             setattr(self, k, np.zeros(E))
         self.gtime = np.zeros(E)
+        self.rtheta = np.zeros(E)
         self.human_times = np.zeros((E, N))
 
     def copy(self):
         o = EnvState(self.E, self.N)
-        for k in self.FIELDS_H + self.FIELDS_R + ("gtime", "human_times"):
+        for k in self.FIELDS_H + self.FIELDS_R + ("gtime", "rtheta", "human_times"):
             setattr(o, k, getattr(self, k).copy())
         return o
 
@@ -137,7 +139,7 @@ def env_step(cfg, st, ax, ay, update=True, given_v=None):
                               _p(st.hpx, d), _p(st.hpy, d), _p(st.hvx, d), _p(st.hvy, d),
                               _p(st.hgx, d), _p(st.hgy, d), _p(st.hr, d), _p(st.hvpref, d),
                               _p(st.rpx, d), _p(st.rpy, d), _p(st.rvx, d), _p(st.rvy, d),
-                              _p(st.rgx, d), _p(st.rgy, d), _p(st.rr, d),
+                              _p(st.rgx, d), _p(st.rgy, d), _p(st.rr, d), _p(st.rtheta, d),
                               _p(st.gtime, d), _p(st.human_times, d),
                               _p(ax, d), _p(ay, d), _p(gv, d),
                               _p(reward, d), _p(done, C.c_uint8), _p(info, C.c_uint8), _p(dmin, d),

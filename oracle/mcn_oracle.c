@@ -42,6 +42,7 @@
  *   - ORCA velocities are float32 values widened to double
  *     (rvo2 returns C floats through Cython).
  */
+#define _GNU_SOURCE
 #include <math.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -306,6 +307,7 @@ typedef struct {
     double orca_safety_space;
     float  orca_neighbor_dist; int orca_max_neighbors;
     float  orca_time_horizon;  float orca_max_speed;
+    int    robot_unicycle;       /* robot action is (v, r): crowd_sim.py:353-355, agent.py:110-135 */
 } mcn_oracle_cfg;
 
 /*
@@ -319,7 +321,7 @@ void mcn_oracle_env_step(const mcn_oracle_cfg *c, int E, int N, int update,
                          double *hpx, double *hpy, double *hvx, double *hvy,
                          const double *hgx, const double *hgy, const double *hr, const double *hvpref,
                          double *rpx, double *rpy, double *rvx, double *rvy,
-                         const double *rgx, const double *rgy, const double *rr,
+                         const double *rgx, const double *rgy, const double *rr, double *rtheta /* [E] or NULL */,
                          double *gtime, double *human_times /* [E*N] or NULL */,
                          const double *ax, const double *ay, const double *given_v,
                          double *reward, uint8_t *done, uint8_t *info, double *dmin_out, int32_t *hh_count,
@@ -368,9 +370,14 @@ void mcn_oracle_env_step(const mcn_oracle_cfg *c, int E, int N, int update,
 
         /* ---- robot-human swept test (crowd_sim.py:345-365) ---- */
         double dmin = INFINITY; int collision = 0;
+        double eax = ax[e], eay = ay[e];        /* robot velocity seen by the swept test */
+        if (c->robot_unicycle) {
+            eax = ax[e] * cos(ay[e] + rtheta[e]);
+            eay = ax[e] * sin(ay[e] + rtheta[e]);
+        }
         for (int i = 0; i < N; ++i) {
             const double px = hpx[b + i] - rpx[e], py = hpy[b + i] - rpy[e];
-            const double vx = hvx[b + i] - ax[e], vy = hvy[b + i] - ay[e];
+            const double vx = hvx[b + i] - eax, vy = hvy[b + i] - eay;
             const double ex = px + vx * dt, ey = py + vy * dt;
             const double cd = mcn_oracle_point_to_segment_dist(px, py, ex, ey, 0, 0) - hr[b + i] - rr[e];
             if (cd < 0) collision = 1;
@@ -389,7 +396,16 @@ void mcn_oracle_env_step(const mcn_oracle_cfg *c, int E, int N, int update,
         }
 
         /* ---- goal test + ladder (crowd_sim.py:379-403) ---- */
-        const double endx = rpx[e] + ax[e] * dt, endy = rpy[e] + ay[e] * dt;
+        double endx, endy, nrvx = ax[e], nrvy = ay[e], nth = 0;
+        if (c->robot_unicycle) {
+            const double th = rtheta[e] + ay[e];                       /* agent.py:115-118 */
+            endx = rpx[e] + cos(th) * ax[e] * dt; endy = rpy[e] + sin(th) * ax[e] * dt;
+            nth = fmod(rtheta[e] + ay[e], 2 * M_PI);                   /* agent.py:133, Python % */
+            if (nth != 0 && nth < 0) nth += 2 * M_PI;
+            nrvx = ax[e] * cos(nth); nrvy = ax[e] * sin(nth);
+        } else {
+            endx = rpx[e] + ax[e] * dt; endy = rpy[e] + ay[e] * dt;
+        }
         const int reaching = norm2(endx - rgx[e], endy - rgy[e]) < rr[e];
         double rew; uint8_t dn, inf;
         if (gtime[e] >= c->time_limit - 1)   { rew = 0; dn = 1; inf = MCN_INFO_TIMEOUT; }
@@ -401,7 +417,8 @@ void mcn_oracle_env_step(const mcn_oracle_cfg *c, int E, int N, int update,
 
         /* ---- integrate or look ahead ---- */
         if (update) {
-            rpx[e] = endx; rpy[e] = endy; rvx[e] = ax[e]; rvy[e] = ay[e];
+            rpx[e] = endx; rpy[e] = endy; rvx[e] = nrvx; rvy[e] = nrvy;
+            if (c->robot_unicycle) rtheta[e] = nth;
             for (int i = 0; i < N; ++i) {
                 hpx[b + i] = hpx[b + i] + hax[i] * dt; hpy[b + i] = hpy[b + i] + hay[i] * dt;
                 hvx[b + i] = hax[i]; hvy[b + i] = hay[i];

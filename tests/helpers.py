@@ -63,7 +63,7 @@ def upload(env, st):
     env.rpos.copy_(t(np.stack([st.rpx, st.rpy], -1))); env.rvel.copy_(t(np.stack([st.rvx, st.rvy], -1)))
     env.rgoal.copy_(t(np.stack([st.rgx, st.rgy], -1)))
     env.rrad.copy_(t(st.rr)); env.rvpref.fill_(1.0)
-    env.gtime.copy_(t(st.gtime)); env.human_times.copy_(t(st.human_times))
+    env.gtime.copy_(t(st.gtime)); env.human_times.copy_(t(st.human_times)); env.rtheta.copy_(t(st.rtheta))
     env.human_num = st.N
 
 
@@ -76,7 +76,7 @@ def download(env):
     rp, rv, rg = c(env.rpos), c(env.rvel), c(env.rgoal)
     st.rpx[:], st.rpy[:], st.rvx[:], st.rvy[:] = rp[:, 0], rp[:, 1], rv[:, 0], rv[:, 1]
     st.rgx[:], st.rgy[:], st.rr[:] = rg[:, 0], rg[:, 1], c(env.rrad)
-    st.gtime[:] = c(env.gtime); st.human_times[:] = c(env.human_times)
+    st.gtime[:] = c(env.gtime); st.human_times[:] = c(env.human_times); st.rtheta[:] = c(env.rtheta)
     return st
 
 
@@ -98,4 +98,5 @@ def oracle_cfg_for(env, human_policy=cport.HUMANS_ORCA):
                              discomfort_dist=env.discomfort_dist,
                              discomfort_penalty_factor=env.discomfort_penalty_factor,
                              robot_visible=1 if env.robot.visible else 0, human_policy=human_policy,
-                             count_hh=1 if env.count_hh else 0, track_human_times=1 if env.track_human_times else 0)
+                             count_hh=1 if env.count_hh else 0, track_human_times=1 if env.track_human_times else 0,
+                             robot_unicycle=1 if getattr(env.robot, "kinematics", "") == "unicycle" else 0)

@@ -153,3 +153,47 @@ def test_rollout_4096x5_bitexact_trajectory():
         done_total += int(ref["done"].sum())
     H.assert_state_equal(H.download(env), st, what="after %d steps" % T)
     assert done_total > 0
+
+
+def test_unicycle_robot_matches_oracle_and_reference(golden_dir):
+    """Robot with (v, r) actions (agent.py:110-135, crowd_sim.py:353-355).  cos/sin differ between numpy, libm
+    and the device by an ulp, so float state is held to 1e-12; masks stay exact on these inputs."""
+    torch = _torch()
+    rng = np.random.RandomState(77)
+    E, N = 500, 5
+    env = H.make_vec_env(E, N, kinematics="unicycle")
+    st = H.random_state(rng, E, N)
+    st.rtheta[:] = rng.uniform(-7, 7, E)
+    v, r = rng.uniform(0, 1, E), rng.uniform(-np.pi / 4, np.pi / 4, E)
+    H.upload(env, st)
+    ob, reward, done, info = env.step(torch.from_numpy(np.stack([v, r], -1)).to(env.device))
+    ref_st = st.copy()
+    ref = cport.env_step(H.oracle_cfg_for(env), ref_st, v, r, update=True)
+    assert np.array_equal(done.cpu().numpy(), ref["done"]) and np.array_equal(info.cpu().numpy(), ref["info"])
+    np.testing.assert_allclose(reward.cpu().numpy(), ref["reward"], rtol=0, atol=1e-12)
+    got = H.download(env)
+    for k in ("rpx", "rpy", "rvx", "rvy", "rtheta", "hpx", "hpy", "gtime"):
+        np.testing.assert_allclose(getattr(got, k), getattr(ref_st, k), rtol=0, atol=1e-12, err_msg=k)
+    # recorded from the real reference (ModelCrowdSim.step with an ActionRot robot)
+    g = np.load(os.path.join(golden_dir, "g2_step_unicycle.npz"))
+    for N in np.unique(g["N"]):
+        sel = np.where((g["N"] == N) & (g["update"] == 1))[0]
+        E, N = len(sel), int(N)
+        env = H.make_vec_env(E, N, kinematics="unicycle")
+        env.count_hh = False
+        st = cport.EnvState(E, N)
+        h, rb = g["hum_in"][sel][:, :N], g["rob_in"][sel]
+        st.hpx[:], st.hpy[:], st.hvx[:], st.hvy[:], st.hr[:] = h[..., 0], h[..., 1], h[..., 2], h[..., 3], h[..., 4]
+        st.rpx[:], st.rpy[:], st.rvx[:], st.rvy[:], st.rr[:] = rb[:, 0], rb[:, 1], rb[:, 2], rb[:, 3], rb[:, 4]
+        st.rgx[:], st.rgy[:], st.rtheta[:] = rb[:, 5], rb[:, 6], rb[:, 8]
+        st.gtime[:] = g["time"][sel]
+        H.upload(env, st)
+        gv = torch.from_numpy(g["given_v"][sel][:, :N].copy()).to(env.device)
+        ob, reward, done, info = env.step(torch.from_numpy(g["act"][sel]).to(env.device), given_v=gv)
+        assert np.array_equal(done.cpu().numpy(), g["done"][sel].astype(np.uint8))
+        assert np.array_equal(info.cpu().numpy(), g["info"][sel].astype(np.uint8))
+        np.testing.assert_allclose(reward.cpu().numpy(), g["reward"][sel], rtol=0, atol=1e-12)
+        ro = g["rob_out"][sel]
+        np.testing.assert_allclose(env.rpos.cpu().numpy(), ro[:, 0:2], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(env.rvel.cpu().numpy(), ro[:, 2:4], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(env.rtheta.cpu().numpy(), ro[:, 8], rtol=0, atol=1e-12)

@@ -16,10 +16,12 @@ def _load_state(g, i):
     st.hgx[0], st.hgy[0], st.hvpref[0] = h[:, 5], h[:, 6], h[:, 7]
     st.rpx[0], st.rpy[0], st.rvx[0], st.rvy[0], st.rr[0], st.rgx[0], st.rgy[0] = r[0], r[1], r[2], r[3], r[4], r[5], r[6]
     st.gtime[0] = g["time"][i]
+    st.rtheta[0] = r[8]
     return st, N
 
 
 @pytest.mark.parametrize("name,policy,tol", [("g2_step_given", cport.HUMANS_GIVEN, 0.0),
+                                             ("g2_step_unicycle", cport.HUMANS_GIVEN, 1e-14),
                                              ("g2_step_linear", cport.HUMANS_LINEAR, 1e-14),
                                              ("g2_step_orca", cport.HUMANS_ORCA, 0.0),
                                              ("g2_step_orca_visible", cport.HUMANS_ORCA, 0.0)])
@@ -28,7 +30,8 @@ def test_env_step_oracle_matches_reference(name, policy, tol, golden_dir):
     vis = int(bool(g["robot_visible"]))
     for i in range(len(g["N"])):
         st, N = _load_state(g, i)
-        cfg = cport.default_cfg(robot_visible=vis, human_policy=policy, count_hh=int(policy != cport.HUMANS_GIVEN))
+        cfg = cport.default_cfg(robot_visible=vis, human_policy=policy, count_hh=int(policy != cport.HUMANS_GIVEN),
+                                robot_unicycle=int("unicycle" in name))
         upd = bool(g["update"][i])
         out = cport.env_step(cfg, st, g["act"][i][:1].copy(), g["act"][i][1:2].copy(), update=upd,
                              given_v=g["given_v"][i][:N].copy())
@@ -40,7 +43,9 @@ def test_env_step_oracle_matches_reference(name, policy, tol, golden_dir):
             ho, ro = g["hum_out"][i][:N], g["rob_out"][i]
             got = np.stack([st.hpx[0], st.hpy[0], st.hvx[0], st.hvy[0]], 1)
             np.testing.assert_allclose(got, ho[:, 0:4], rtol=0, atol=tol)
-            np.testing.assert_allclose([st.rpx[0], st.rpy[0], st.rvx[0], st.rvy[0]], ro[0:4], rtol=0, atol=0)
+            np.testing.assert_allclose([st.rpx[0], st.rpy[0], st.rvx[0], st.rvy[0]], ro[0:4], rtol=0, atol=tol)
+            if "unicycle" in name:
+                assert abs(st.rtheta[0] - ro[8]) <= tol
             assert st.gtime[0] == g["time_out"][i]
             if policy != cport.HUMANS_GIVEN:
                 np.testing.assert_array_equal(st.human_times[0], g["human_times"][i][:N])

@@ -154,7 +154,7 @@ def _random_scene(rng, env, N, mode):
     return ActionXY(sp * np.cos(aa), sp * np.sin(aa))
 
 
-def _g2(name, cls_name, humans_policy, robot_visible, n_samples, seed):
+def _g2(name, cls_name, humans_policy, robot_visible, n_samples, seed, unicycle=False):
     rng = np.random.RandomState(seed)
     rows = {k: [] for k in ("N", "update", "time", "rob_in", "hum_in", "act", "given_v", "reward", "done", "info",
                             "dmin", "rob_out", "hum_out", "obs", "time_out", "human_times")}
@@ -162,6 +162,8 @@ def _g2(name, cls_name, humans_policy, robot_visible, n_samples, seed):
         for rnd in (False, True):
             env, robot, pol = make_env(cls_name, robot_policy="orca", humans_policy=humans_policy,
                                        human_num=N, randomize=rnd, robot_visible=robot_visible)
+            if unicycle:
+                robot.kinematics = "unicycle"          # Agent.kinematics, normally copied from the policy (agent.py:36)
             for s in range(n_samples):
                 if cls_name == "CrowdSim":
                     env.reset("test", s % 7)        # fresh Human objects -> fresh ORCA sims
@@ -169,6 +171,10 @@ def _g2(name, cls_name, humans_policy, robot_visible, n_samples, seed):
                     env.reset("test", no_random_gen=True)
                 mode = ("spread", "close", "crowded", "neargoal")[s % 4]
                 action = _random_scene(rng, env, N, mode)
+                if unicycle:
+                    from crowd_sim.envs.utils.action import ActionRot
+                    env.robot.theta = rng.uniform(-7, 7)
+                    action = ActionRot(rng.uniform(0, 1.0), rng.uniform(-np.pi / 4, np.pi / 4))
                 for h in env.humans:
                     h.time_step = env.time_step
                     h.policy.time_step = env.time_step
@@ -184,7 +190,7 @@ def _g2(name, cls_name, humans_policy, robot_visible, n_samples, seed):
                 rob_out, hum_out = full_state_rows(env)
                 rows["N"].append(N); rows["update"].append(update); rows["time"].append(t_in)
                 rows["rob_in"].append(rob_in); rows["hum_in"].append(np.pad(hum_in, ((0, 10 - N), (0, 0))))
-                rows["act"].append([action.vx, action.vy]); rows["given_v"].append(np.pad(gv, ((0, 10 - N), (0, 0))))
+                rows["act"].append([action[0], action[1]]); rows["given_v"].append(np.pad(gv, ((0, 10 - N), (0, 0))))
                 rows["reward"].append(reward); rows["done"].append(done); rows["info"].append(info_code(info))
                 rows["dmin"].append(getattr(info, "min_dist", np.nan))
                 rows["rob_out"].append(rob_out); rows["hum_out"].append(np.pad(hum_out, ((0, 10 - N), (0, 0))))
@@ -205,6 +211,7 @@ def g2_step():
     _g2("g2_step_linear", "CrowdSim", "linear", False, 160, 12)
     _g2("g2_step_orca", "CrowdSim", "orca", False, 200, 13)
     _g2("g2_step_orca_visible", "CrowdSim", "orca", True, 120, 14)
+    _g2("g2_step_unicycle", "ModelCrowdSim", "orca", False, 120, 15, unicycle=True)
 
 
 def g3_p2s():

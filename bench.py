@@ -254,12 +254,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # MCN_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks (collectives on
+    # CPU copies, ranks share devices); the driver's runs use the default: nccl (= RCCL), one GPU per rank
+    backend = os.environ.get("MCN_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    cdev = device if backend == "nccl" else torch.device("cpu")        # where collective buffers live
     E, N, K, W = args.envs, args.humans, args.steps, args.warmup
     E_total = E * world
 
@@ -273,48 +274,60 @@ def main():
 
     use_graph = not args.no_graph
     if use_graph:
+        # captured BEFORE the process group exists: ranks are independent until the final gather, and an
+        # RCCL watchdog thread polling events during stream capture is a known way to break a capture
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             for t in range(K):
                 env.step(acts[W + t])
 
+    rb = env.rollout_buffers
+    gathered = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+        gathered = torch.empty(world * E, 3, dtype=torch.float32, device=cdev)
+        # warm the communicator with the exact collective used later (lazy channel setup stays out of the timing)
+        dist.all_gather_into_tensor(gathered, torch.zeros(E, 3, dtype=torch.float32, device=cdev))
+
     def barrier():
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
-    gathered = None
+    ev_s, ev_e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
+    ev_s.record()
     if use_graph:
         graph.replay()
     else:
         for t in range(K):
             env.step(acts[W + t])
+    ev_e.record()
     if world > 1:
-        # the path's one exchange: episode returns + outcome codes + counts, one fused buffer
-        import torch.distributed as dist
-        rb = env.rollout_buffers
+        # the path's one exchange: episode returns + outcome codes + counts, one fused buffer, one collective
         packed = torch.stack([rb["fin_return"][0], rb["fin_info"][0].double(), rb["fin_count"].double()], 1).float()
-        gathered = torch.empty(world * E, 3, dtype=torch.float32, device=device)
-        dist.all_gather_into_tensor(gathered, packed)
+        dist.all_gather_into_tensor(gathered, packed.to(cdev))
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # dominant-kernel duration: HIP events (launch stream) bracketing the K back-to-back launches of the timed region
+    kernel_ms = ev_s.elapsed_time(ev_e) / K
 
     rb = env.rollout_buffers
     episodes = int(rb["fin_count"].sum().item())
     mean_ret = float(rb["fin_return"][0][rb["fin_count"] > 0].mean().item()) if episodes else float("nan")
 
-    # dominant-kernel duration, live, HIP events on the launch stream (eager launches of the same kernel)
-    avg_ms, best_ms = time_kernel_events(env, acts[W:], min(K, 1000))
-    roof = roofline_entry(E, N, avg_ms, {"best_launch_us": round(best_ms * 1e3, 3),
-                                         "timing": "HIP events around a hipGraph of %d launches" % min(K, 1000)})
+    roof = roofline_entry(E, N, kernel_ms, {"timing": "HIP events around the %d launches of the timed region (%s)" % (
+        K, "one hipGraph" if use_graph else "eager")})
 
     result = {
         "metric": "env-steps/sec (whole node), 5-human CrowdSim x batched envs",
@@ -327,6 +340,7 @@ def main():
                    "envs_per_gpu": E, "humans": N, "launch": "hipGraph" if use_graph else "eager",
                    "parallelism": "env-shard x%d, no per-step collective" % world},
         "episodes_finished": episodes, "mean_discounted_return": round(mean_ret, 6),
+        "gathered_episode_records": None if gathered is None else int((gathered[:, 2] > 0).sum().item()),
         "roofline": roof,
     }
 
@@ -364,7 +378,6 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
-        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -40,6 +40,10 @@ _MAP = {
     "crowd_nav.policy.sarl": "modelcrowdnav_amd.policy.sarl",
     "crowd_nav.policy.policy_factory": "modelcrowdnav_amd.policy.policy_factory",
     "crowd_nav.policy.world_model": "modelcrowdnav_amd.policy.world_model",
+    "crowd_nav.utils": "modelcrowdnav_amd.utils",
+    "crowd_nav.utils.explorer": "modelcrowdnav_amd.utils.explorer",
+    "crowd_nav.utils.memory": "modelcrowdnav_amd.utils.memory",
+    "crowd_nav.utils.trainer": "modelcrowdnav_amd.utils.trainer",
     "sgan.models": "modelcrowdnav_amd.sgan.models",
     "sgan.utils": "modelcrowdnav_amd.sgan.utils",
 }

@@ -58,3 +58,22 @@ class ORCA(Policy):
         v = d_out.cpu().numpy()
         self.last_state = state
         return ActionXY(float(v[0]), float(v[1]))
+
+    def predict_batch(self, env):
+        """ORCA-driven robot for all E envs of a VecCrowdSim (the imitation-learning demonstrator, train.py:150-160):
+        one mcn_orca_batch launch with the robot as agent 0 and every human as a candidate neighbour."""
+        import torch
+        from ... import _hip
+        E, N, dev = env.num_envs, env._alloc_N, env.device
+        f = torch.float32
+        extra = 0.01 + float(self.safety_space)
+        me = torch.cat([env.rpos.to(f), env.rvel.to(f), (env.rrad + extra).to(f).unsqueeze(1),
+                        env.rvpref.to(f).unsqueeze(1), (env.rgoal - env.rpos).to(f)], 1).contiguous()      # [E,8]
+        oth = torch.cat([env.hpos.to(f), env.hvel.to(f), (env.hrad + extra).to(f).unsqueeze(2)], 2).contiguous()
+        n = torch.full((E,), N, dtype=torch.int32, device=dev)
+        out = torch.empty(E, 2, dtype=f, device=dev)
+        _hip.check(_hip.lib.mcn_orca_batch(_hip.ptr(me), _hip.ptr(oth), _hip.ptr(n), _hip.ptr(out), E, N,
+                                           float(self.neighbor_dist), int(self.max_neighbors),
+                                           float(self.time_horizon), float(env.time_step), _hip.stream_ptr(dev)),
+                   "mcn_orca_batch")
+        return out.double(), None

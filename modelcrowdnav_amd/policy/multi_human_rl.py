@@ -119,6 +119,17 @@ class MultiHumanRL(CADRL):
             raise NotImplementedError("occupancy maps (with_om) are outside this build's scope")
         return self.rotate(rows)
 
+    def transform_batch(self, env):
+        """`transform` for every env of a VecCrowdSim: [E,N,13] float32 rotated joint states (what the reference
+        stores as `last_state` in train phase, multi_human_rl.py:60-61)."""
+        E, N = env.num_envs, env._alloc_N
+        f = torch.float32
+        rob = torch.cat([env.rpos, env.rvel, env.rrad.unsqueeze(1), env.rgoal, env.rvpref.unsqueeze(1),
+                         env.rtheta.unsqueeze(1)], 1).to(f)                                  # [E,9]
+        hum = torch.cat([env.hpos, env.hvel, env.hrad.unsqueeze(2)], 2).to(f)                 # [E,N,5]
+        rows = torch.cat([rob.unsqueeze(1).expand(E, N, 9), hum], 2).reshape(E * N, 14)
+        return self.rotate(rows).view(E, N, 13)
+
     def input_dim(self):
         return self.joint_state_dim + (self.cell_num ** 2 * self.om_channel_size if self.with_om else 0)
 

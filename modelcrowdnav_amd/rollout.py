@@ -25,10 +25,48 @@ def average(xs):
 
 
 class VecExplorer(object):
-    def __init__(self, env, robot, device=None, gamma=0.9, policy=None):
+    def __init__(self, env, robot, device=None, gamma=0.9, policy=None, memory=None, target_policy=None):
         self.env, self.robot, self.gamma = env, robot, gamma
         self.device = device or env.device
         self.policy = policy if policy is not None else robot.policy
+        self.memory = memory
+        self.target_policy = target_policy       # supplies transform() in imitation learning (explorer.py:163)
+        self.target_model = None
+
+    def update_target_model(self, target_model):
+        import copy
+        self.target_model = copy.deepcopy(target_model)
+
+    def _value_targets(self, states, rewards, dones, infos, imitation_learning):
+        """explorer.py:153-186 for a whole batched rollout.  states [T,E,N,13] f32, rewards [T,E] f64,
+        dones [T,E] bool, infos [T,E] u8.  Returns (states [M,N,13], values [M]) of the steps that belong to
+        episodes ending in ReachGoal or Collision (only those feed the memory, explorer.py:107-110)."""
+        T, E = rewards.shape
+        v_pref = float(self.robot.v_pref)
+        gbar = pow(self.gamma, self.env.time_step * v_pref)
+        keep = torch.zeros(T, E, dtype=torch.bool, device=rewards.device)
+        values = torch.zeros(T, E, dtype=torch.float64, device=rewards.device)
+        good_end = (infos == _hip.INFO_REACHGOAL) | (infos == _hip.INFO_COLLISION)
+        if not imitation_learning:
+            with torch.no_grad():
+                nxt = self.target_model(states[1:].reshape(-1, states.shape[2], states.shape[3]).to(self.device))
+            nxt = torch.cat([nxt.view(T - 1, E).double(), torch.zeros(1, E, dtype=torch.float64, device=nxt.device)], 0)
+        ep_ok = torch.zeros(E, dtype=torch.bool, device=rewards.device)      # episode containing step t ends well
+        run = torch.zeros(E, dtype=torch.float64, device=rewards.device)     # discounted tail sum (IL)
+        for t in range(T - 1, -1, -1):
+            d = dones[t]
+            ep_ok = torch.where(d, good_end[t], ep_ok)          # a done at t starts (going backwards) a new episode
+            if imitation_learning:
+                run = torch.where(d, rewards[t], rewards[t] + gbar * run)
+                values[t] = run
+            else:
+                values[t] = torch.where(d, rewards[t], rewards[t] + gbar * nxt[t])
+            keep[t] = ep_ok
+        # steps after the last done of an env belong to an unfinished episode: ep_ok is False there by construction
+        idx = keep.t().reshape(-1).nonzero().squeeze(1)           # (env, time) order
+        flat_states = states.permute(1, 0, 2, 3).reshape(T * E, states.shape[2], states.shape[3])
+        flat_values = values.t().reshape(-1)
+        return flat_states[idx], flat_values[idx].float()
 
     def _actions(self, step_actions):
         if step_actions is not None:
@@ -36,8 +74,9 @@ class VecExplorer(object):
         a, _ = self.policy.predict_batch(self.env)
         return a
 
-    def run_k_episodes(self, k, phase, episode=None, print_failure=False, returnRate=True, returnNav=False,
-                       action_fn=None, max_steps=None, total_envs=None):
+    def run_k_episodes(self, k, phase, update_memory=False, imitation_learning=False, episode=None,
+                       print_failure=False, returnRate=True, returnNav=False, action_fn=None, max_steps=None,
+                       total_envs=None):
         """Returns what Explorer.run_k_episodes returns (explorer.py:146-151):
         (avg cumulative reward, success rate, collision rate, timeout rate[, avg nav time])
         or counts instead of rates when returnRate is False.  `action_fn(env, t) -> [E,2]` overrides the
@@ -72,15 +111,33 @@ class VecExplorer(object):
                                   first_cases=(mine[:, 1] if rounds > 1 else mine[:, 0]), fin_slots=rounds)
         horizon = int(round(env.time_limit / env.time_step)) + 2
         limit = max_steps if max_steps is not None else rounds * horizon
+        if update_memory and (self.memory is None or self.gamma is None):
+            raise ValueError("Memory or gamma value is not set!")
+        transformer = (self.target_policy if imitation_learning else self.policy) if update_memory else None
+        rec_s, rec_r, rec_d, rec_i = [], [], [], []
         t = 0
         while t < limit:
+            if update_memory:
+                rec_s.append(transformer.transform_batch(env))           # the state the action is chosen in
             a = action_fn(env, t) if action_fn is not None else self._actions(None)
             env.step(a)
+            if update_memory:
+                rec_r.append(env.reward.clone()); rec_d.append(env.done.bool()); rec_i.append(env.info.clone())
             t += 1
             if t % 32 == 0 and int(bufs["fin_count"].min().item()) >= rounds:
                 break
         if int(bufs["fin_count"].min().item()) < rounds:
             raise RuntimeError("rollout did not finish %d episodes per env within %d steps" % (rounds, limit))
+        if update_memory:
+            # only the first `rounds` episodes of each env are the k requested ones: cut each env's trace there
+            dones = torch.stack(rec_d)
+            order = torch.cumsum(dones.long(), 0) - dones.long()          # episode number each step belongs to
+            valid = order < rounds
+            gidx = (order * E_total + lo + torch.arange(E_local, device=dones.device).unsqueeze(0))
+            valid &= gidx < k
+            s, v = self._value_targets(torch.stack(rec_s), torch.stack(rec_r), dones & valid, torch.stack(rec_i),
+                                       imitation_learning)
+            self.memory.push_batch(s, v)
         env.case_counter[phase] = (first + k) % size
         # records in global episode order: episode g = r * E_total + global_env
         rec = mdist.gather_records(bufs["fin_return"].t().contiguous(), bufs["fin_info"].t().contiguous(),

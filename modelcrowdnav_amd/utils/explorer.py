@@ -1,0 +1,105 @@
+"""Sequential Explorer with the reference's call surface (crowd_nav/utils/explorer.py:11-192), for drivers
+that run one E = 1 gym env (train.py:120-246, test.py:73-109).  The batched equivalent is
+modelcrowdnav_amd.rollout.VecExplorer; this class exists so `Explorer(env, robot, device, memory, gamma,
+target_policy)` keeps working after `dropin.install()`.
+
+Not reproduced: the SGAN text-cache / raw-observation side channels (`cacheFile`, `raw_memory`,
+`update_raw_ob`, explorer.py:71-85,112-121), which belong to the dataset tooling outside this build's scope.
+"""
+import copy
+import logging
+
+import torch
+
+from ..envs.utils.action import ActionRot, ActionXY
+from ..envs.utils import info as I
+
+
+def average(xs):
+    return sum(xs) / len(xs) if xs else 0
+
+
+class Explorer(object):
+    def __init__(self, env, robot, device, memory=None, gamma=None, target_policy=None):
+        self.env, self.robot, self.device = env, robot, device
+        self.memory, self.gamma, self.target_policy = memory, gamma, target_policy
+        self.target_model = None
+        self.raw_memory = None
+        self.rawob = None
+
+    def update_target_model(self, target_model):
+        self.target_model = copy.deepcopy(target_model)
+
+    def _discount(self, steps):
+        return pow(self.gamma, steps * self.robot.time_step * self.robot.v_pref)
+
+    def run_k_episodes(self, k, phase, update_memory=False, imitation_learning=False, episode=None,
+                       print_failure=False, update_raw_ob=False, stay=False, returnRate=True, test_case=None,
+                       returnNav=False, cacheFile=None):
+        self.robot.policy.set_phase(phase)
+        outcome = {"success": [], "collision": [], "timeout": []}       # (episode index, time)
+        too_close, min_dist, returns = 0, [], []
+        for i in range(k):
+            ob = self.env.reset(phase, test_case=test_case)
+            done, states, actions, rewards = False, [], [], []
+            while not done:
+                if stay:
+                    action = ActionXY(0, 0) if self.robot.policy.kinematics == "holonomic" else ActionRot(0, 0)
+                else:
+                    action = self.robot.act(ob)
+                ob, reward, done, info = self.env.step(action)
+                states.append(self.robot.policy.last_state)
+                actions.append(action)
+                rewards.append(reward)
+                if isinstance(info, I.Danger):
+                    too_close += 1
+                    min_dist.append(info.min_dist)
+            if isinstance(info, I.ReachGoal):
+                outcome["success"].append((i, self.env.global_time))
+            elif isinstance(info, I.Collision):
+                outcome["collision"].append((i, self.env.global_time))
+            elif isinstance(info, I.Timeout):
+                outcome["timeout"].append((i, self.env.time_limit))
+            else:
+                raise ValueError("Invalid end signal from environment")
+            if update_memory and isinstance(info, (I.ReachGoal, I.Collision)):
+                self.update_memory(states, actions, rewards, imitation_learning)
+            returns.append(sum([self._discount(t) * r for t, r in enumerate(rewards)]))
+
+        success, collision = len(outcome["success"]), len(outcome["collision"])
+        assert success + collision + len(outcome["timeout"]) == k
+        times = [t for _, t in outcome["success"]]
+        avg_nav_time = sum(times) / len(times) if times else self.env.time_limit
+        extra = "" if episode is None else "in episode {} ".format(episode)
+        if not stay:
+            logging.info("%-5s %shas success rate: %.2f, collision rate: %.2f, nav time: %.2f, total reward: %.4f",
+                         phase.upper(), extra, success / k, collision / k, avg_nav_time, average(returns))
+        if phase in ("val", "test"):
+            total_steps = sum(t for v in outcome.values() for _, t in v) / self.robot.time_step
+            logging.info("Frequency of being in danger: %.2f and average min separate distance in danger: %.2f",
+                         too_close / total_steps, average(min_dist))
+        if print_failure:
+            logging.info("Collision cases: " + " ".join(str(i) for i, _ in outcome["collision"]))
+            logging.info("Timeout cases: " + " ".join(str(i) for i, _ in outcome["timeout"]))
+        timeout_n = k - success - collision
+        if returnRate and returnNav:
+            return average(returns), success / k, collision / k, timeout_n / k, avg_nav_time
+        if returnRate:
+            return average(returns), success / k, collision / k, timeout_n / k
+        return average(returns), success, collision, timeout_n
+
+    def update_memory(self, states, actions, rewards, imitation_learning=False):
+        """explorer.py:153-186: push (state, value) for every step of one finished episode."""
+        if self.memory is None or self.gamma is None:
+            raise ValueError("Memory or gamma value is not set!")
+        last = len(states) - 1
+        for i, state in enumerate(states):
+            if imitation_learning:
+                state = self.target_policy.transform(state)
+                value = sum([self._discount(max(t - i, 0)) * r * (1 if t >= i else 0) for t, r in enumerate(rewards)])
+            elif i == last:
+                value = rewards[i]
+            else:
+                nxt = self.target_model(states[i + 1].unsqueeze(0)).data.item()
+                value = rewards[i] + self._discount(1) * nxt
+            self.memory.push((state, torch.Tensor([value]).to(self.device)))

@@ -13,6 +13,9 @@ def test_reference_import_paths_resolve():
     from crowd_nav.policy.policy_factory import policy_factory
     from crowd_nav.policy.world_model import SGANWorld, get_generator     # noqa: F401
     from sgan.models import TrajectoryGenerator                 # noqa: F401
+    from crowd_nav.utils.explorer import Explorer                # noqa: F401
+    from crowd_nav.utils.memory import ReplayMemory              # noqa: F401
+    from crowd_nav.utils.trainer import Trainer                  # noqa: F401
     assert set(["sarl", "orca", "linear", "none"]) <= set(policy_factory)
     env = gym.make("CrowdSim-v0")
     assert type(env).__name__ == "CrowdSim"

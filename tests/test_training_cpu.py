@@ -1,0 +1,111 @@
+"""CPU: the next-tier callers -- replay memory ring semantics, trainer steps, and the
+data-parallel gradient all-reduce on world_size-2 gloo."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(seed=0):
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.policy.sarl import SARL
+    torch.manual_seed(seed)
+    p = SARL()
+    p.configure(configs.policy_config())
+    return p.model
+
+
+def test_replay_memory_ring_matches_reference_semantics():
+    from modelcrowdnav_amd.utils.memory import ReplayMemory
+    m = ReplayMemory(5)
+    items = [(torch.full((3, 13), float(i)), torch.tensor([float(i)])) for i in range(8)]
+    for it in items[:3]:
+        m.push(it)
+    assert len(m) == 3 and not m.is_full() and m.position == 3
+    for it in items[3:]:
+        m.push(it)                      # wraps: slots 0..2 now hold items 5,6,7 (memory.py:13-19)
+    assert len(m) == 5 and m.is_full() and m.position == 3
+    assert [float(m[i][1]) for i in range(5)] == [5.0, 6.0, 7.0, 3.0, 4.0]
+    m.push_batch(torch.stack([it[0] for it in items[:4]]), torch.tensor([10.0, 11.0, 12.0, 13.0]))
+    assert [float(m[i][1]) for i in range(5)] == [12.0, 13.0, 7.0, 10.0, 11.0] and m.position == 2
+    s, v = m.sample(4, torch.Generator().manual_seed(0))
+    assert s.shape == (4, 3, 13) and v.shape == (4, 1)
+    m.clear()
+    assert len(m) == 0
+
+
+def test_trainer_reduces_loss():
+    from modelcrowdnav_amd.utils.memory import ReplayMemory
+    from modelcrowdnav_amd.utils.trainer import Trainer
+    model = _model()
+    g = torch.Generator().manual_seed(1)
+    states = torch.randn(200, 5, 13, generator=g)
+    states[:, :, :6] = states[:, :1, :6]
+    values = torch.tanh(states[:, :, 6].mean(1))
+    mem = ReplayMemory(400)
+    mem.push_batch(states, values)
+    tr = Trainer(model, mem, torch.device("cpu"), 100)
+    try:
+        tr.optimize_batch(1)
+        assert False, "learning rate must be set first"
+    except ValueError:
+        pass
+    tr.set_learning_rate(0.01)
+    first = tr.optimize_epoch(1)
+    for _ in range(10):
+        last = tr.optimize_epoch(1)
+    assert last < first
+    assert tr.optimize_batch(3) > 0
+
+
+def _dp_worker(rank, ws, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(ws), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from modelcrowdnav_amd import dist as mdist
+    from modelcrowdnav_amd.utils.memory import ReplayMemory
+    from modelcrowdnav_amd.utils.trainer import Trainer
+    mdist.init_from_env("gloo")
+    torch.set_num_threads(1)
+    model = _model(seed=rank)                   # deliberately different: sync_weights must fix it
+    g = torch.Generator().manual_seed(7)
+    states = torch.randn(64, 5, 13, generator=g)
+    values = torch.randn(64, generator=g)
+    mem = ReplayMemory(32)
+    mem.push_batch(states[rank * 32:(rank + 1) * 32], values[rank * 32:(rank + 1) * 32])
+    tr = Trainer(model, mem, torch.device("cpu"), 32)
+    tr.sync_weights()
+    tr.set_learning_rate(0.05)
+    tr.optimize_epoch(2)                        # batch == whole shard, so the order inside it is irrelevant
+    torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(out_dir, "w%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_trainer_world2(tmp_path):
+    from modelcrowdnav_amd.utils.memory import ReplayMemory
+    from modelcrowdnav_amd.utils.trainer import Trainer
+    port = 29800 + (os.getpid() % 1500)
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    w0 = torch.load(os.path.join(str(tmp_path), "w0.pt"), weights_only=True)
+    w1 = torch.load(os.path.join(str(tmp_path), "w1.pt"), weights_only=True)
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k                      # ranks stay in lock step
+    # single process on the union with the same initial weights (rank 0's seed) must match:
+    # mean over 64 samples == average of the two 32-sample means
+    torch.set_num_threads(1)
+    model = _model(seed=0)
+    g = torch.Generator().manual_seed(7)
+    states = torch.randn(64, 5, 13, generator=g)
+    values = torch.randn(64, generator=g)
+    mem = ReplayMemory(64)
+    mem.push_batch(states, values)
+    tr = Trainer(model, mem, torch.device("cpu"), 64)
+    tr.set_learning_rate(0.05)
+    tr.optimize_epoch(2)
+    for k, v in model.state_dict().items():
+        assert torch.allclose(v, w0[k], rtol=0, atol=2e-6), k

@@ -25,29 +25,9 @@
 #include "orca_device.hpp"
 #include "orca_static.hpp"
 #include "env_step_params.hpp"
+#include "env_common.hpp"
 
 namespace mcn {
-
-__device__ __forceinline__ double norm2(double x0, double x1) { return sqrt(fma(x1, x1, x0 * x0)); }
-
-// crowd_sim/envs/utils/utils.py:4-26 with (x3, y3) = (0, 0), the env's only call shape
-__device__ __forceinline__ double p2s_origin(double x1, double y1, double x2, double y2)
-{
-    const double px = x2 - x1, py = y2 - y1;
-    if (px == 0 && py == 0) return norm2(0.0 - x1, 0.0 - y1);
-    double u = ((0.0 - x1) * px + (0.0 - y1) * py) / (px * px + py * py);
-    if (u > 1) u = 1; else if (u < 0) u = 0;
-    const double x = x1 + u * px, y = y1 + u * py;
-    return norm2(x - 0.0, y - 0.0);
-}
-
-// Python's float % for a positive divisor
-__device__ __forceinline__ double pymod(double a, double m)
-{
-    double r = fmod(a, m);
-    if (r != 0 && r < 0) r += m;
-    return r;
-}
 
 struct GroupCand {
     const float4 *sAg; const float *sRad;   // block-level staged humans
@@ -396,8 +376,13 @@ static void dispatch(const StepParams &p, int blocks, hipStream_t stream)
     }
 }
 
+bool launch_env_step_quad(const StepParams &p, hipStream_t stream);      // env_step_quad.hip
+
 int launch_env_step(const StepParams &p, hipStream_t stream)
 {
+    // <= 4 ORCA neighbours per human: quad-parallel kernel (env_step_quad.hip)
+    if (p.quad_max_envs > 0 && p.E <= p.quad_max_envs && launch_env_step_quad(p, stream))
+        return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
     const int waves_total = (p.E + p.G - 1) / p.G;
     // small batches: one wavefront per workgroup so the grid covers as many CUs as possible
     if (waves_total <= 4096) dispatch<64>(p, waves_total, stream);

@@ -14,6 +14,8 @@ struct StepParams {
     const double *given_v;
     int E, N, G, update, has_roll;
     int nl_cap;   // LDS line slots per lane
+    int quad_max_envs;   // use the quad-parallel kernel up to this batch size (0: never)
+    int quad_split;      // quad kernel: ORCA and pairwise work on two cooperating wavefronts
 };
 
 }  // namespace mcn

@@ -1,0 +1,431 @@
+// env_step_quad.hip -- latency-oriented fused CrowdSim.step for crowds with <= 4 ORCA neighbours per human
+// (human_num <= 5 with an invisible robot: the reference's default configuration, env.config:22,33).
+//
+// Same arithmetic, bit for bit, as env_step.hip; different decomposition.  env_step.hip gives each human one
+// lane, which then builds its 4 half-planes, runs the 4 steps of the incremental LP and (rarely) the 3-D LP one
+// after the other -- a ~2000-instruction dependent chain that sets the latency of a small batch.  Here each
+// human owns a QUAD of lanes, lane k <-> k-th candidate neighbour:
+//   * every lane loads its own candidate straight from L2 and builds ONE half-plane;
+//   * the distance ranking is a handful of DPP quad broadcasts; the half-planes are routed to their sorted slot
+//     with one ds_permute per component and then shared by quad broadcast, so every lane holds all four;
+//   * the 1-D LP on line i (RVO2 linearProgram1) depends on the lines before it and on the preferred velocity,
+//     but NOT on the running result -- only the cheap violation test does.  So lane i solves line i's 1-D LP
+//     speculatively, all four at once, and the incremental LP collapses into four compare-and-take steps.
+//     The same holds for the 3-D LP: the candidate of line i (project lines < i, direction-optimising 2-D LP)
+//     is independent of the running result, so the quad computes all candidates in parallel as well;
+//   * the swept-circle test runs on lane 0 of each quad, the human-human overlap tests one pair per lane.
+// Control flow is uniform across the lanes of a quad (run-time line index, predicated inner steps), so the
+// parallelism is real rather than divergence.  No LDS, no barrier: operands shared inside an env are fetched
+// by every lane that needs them (same-address loads coalesce) and per-env results are recomputed redundantly.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mcn.h"
+#include "orca_device.hpp"
+#include "orca_static.hpp"
+#include "env_step_params.hpp"
+#include "env_common.hpp"
+
+namespace mcn {
+
+// quad broadcast of lane I (0..3) of every quad: a DPP move, no LDS traffic
+template <int I>
+__device__ __forceinline__ int qbi(int v) { return __builtin_amdgcn_update_dpp(0, v, I * 0x55, 0xf, 0xf, false); }
+template <int I>
+__device__ __forceinline__ float qbf(float v) { return __builtin_bit_cast(float, qbi<I>(__builtin_bit_cast(int, v))); }
+template <int I>
+__device__ __forceinline__ double qbd(double v)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = qbi<I>((int)b), hi = qbi<I>((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <int I>
+__device__ __forceinline__ float4 qb4(float4 v) { return make_float4(qbf<I>(v.x), qbf<I>(v.y), qbf<I>(v.z), qbf<I>(v.w)); }
+
+__device__ __forceinline__ float4 sel4(const float4 (&L)[4], int i)
+{
+    const float4 a = i == 1 ? L[1] : L[0], b = i == 3 ? L[3] : L[2];
+    return i >= 2 ? b : a;
+}
+
+// linearProgram1 on line `no` (run-time, 0..3) against lines [0, no): uniform code, predicated steps.
+template <bool DIR>
+__device__ __forceinline__ bool lp1_rt(const float4 (&L)[4], int no, float radius, float optx, float opty, float &rx, float &ry)
+{
+    const float4 ln = sel4(L, no);
+    const float dp = dot2(ln.x, ln.y, ln.z, ln.w);
+    const float disc = dp * dp + radius * radius - dot2(ln.x, ln.y, ln.x, ln.y);
+    bool ok = !(disc < 0.0f);
+    const float sq = sqrtf(disc);
+    float tl = -dp - sq;
+    float tr = -dp + sq;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (i < no) {
+            const float4 li = L[i];
+            const float den = det2(ln.z, ln.w, li.z, li.w);
+            const float num = det2(li.z, li.w, ln.x - li.x, ln.y - li.y);
+            if (fabsf(den) <= kRvoEps) {
+                if (num < 0.0f) ok = false;
+            } else {
+                const float t = num / den;
+                if (den >= 0.0f) tr = fminf(tr, t);
+                else             tl = fmaxf(tl, t);
+                if (tl > tr) ok = false;
+            }
+        }
+    }
+    float t;
+    if (DIR) {
+        t = (dot2(optx, opty, ln.z, ln.w) > 0.0f) ? tr : tl;
+    } else {
+        t = dot2(ln.z, ln.w, optx - ln.x, opty - ln.y);
+        if (t < tl) t = tl; else if (t > tr) t = tr;
+    }
+    rx = ln.x + t * ln.z;
+    ry = ln.y + t * ln.w;
+    return ok;
+}
+
+// 3-D LP candidate of line `no` (run-time): project lines [0,no) on it, direction-optimising 2-D LP.
+__device__ __forceinline__ bool lp3_candidate(const float4 (&L)[4], int no, float radius, float &rx, float &ry)
+{
+    const float4 li = sel4(L, no);
+    float4 P[3];
+    int m = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float4 lj = L[j];
+        const float dt = det2(li.z, li.w, lj.z, lj.w);
+        float qx, qy;
+        bool skip = !(j < no);
+        if (fabsf(dt) <= kRvoEps) {
+            if (dot2(li.z, li.w, lj.z, lj.w) > 0.0f) skip = true;
+            qx = 0.5f * (li.x + lj.x); qy = 0.5f * (li.y + lj.y);
+        } else {
+            const float sc = det2(lj.z, lj.w, li.x - lj.x, li.y - lj.y) / dt;
+            qx = li.x + sc * li.z; qy = li.y + sc * li.w;
+        }
+        const float ddx = lj.z - li.z, ddy = lj.w - li.w;
+        const float inv = 1.0f / sqrtf(dot2(ddx, ddy, ddx, ddy));
+        const float4 q = make_float4(qx, qy, ddx * inv, ddy * inv);
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl)
+            if (!skip && sl == m) P[sl] = q;
+        m += skip ? 0 : 1;
+    }
+    const float ox = -li.w, oy = li.z;
+    rx = radius * ox; ry = radius * oy;
+    int fail = m;
+    Lp2Step<0, 3, true>::run(P, m, radius, ox, oy, rx, ry, fail);
+    return fail == m;
+}
+
+// SPLIT = true: the workgroup has two wavefronts working on the same G envs.  Wavefront 0 solves ORCA (float32),
+// wavefront 1 does the float64 swept-circle / overlap tests, the reward ladder and all per-env outputs AT THE
+// SAME TIME; they meet at one barrier (human velocities one way, done flag / reset case the other way through
+// LDS) and wavefront 0 then integrates the humans.  The critical path becomes max(ORCA, pairwise) instead of
+// their sum.  SPLIT = false: one wavefront does both in sequence.
+template <int NT, int VIS, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 128 : 64) void env_step_quad_kernel(const StepParams p)
+{
+    __shared__ int s_dn[16], s_case[16];
+    const int role = SPLIT ? (int)(threadIdx.x >> 6) : -1;      // 0: ORCA, 1: pairwise + ladder, -1: both
+    const bool do_orca = role != 1, do_pair = role != 0;
+    constexpr int NC = NT - 1 + VIS;          // candidates per human, <= 4
+    constexpr int LPE = 4 * NT;               // lanes per env
+    constexpr int G = 64 / LPE;               // envs per wavefront
+    static_assert(NC >= 0 && NC <= 4, "quad kernel handles at most 4 ORCA neighbours");
+    const int lane = threadIdx.x & 63;
+    const int g = lane / LPE;
+    const int r = lane - g * LPE;
+    const int h = r >> 2, k = r & 3;
+    const long e = (long)blockIdx.x * G + g;
+    const bool active = (g < G) && (e < p.E);
+    const long eb = active ? e : 0;
+    const long a = eb * NT + h;
+    const mcn_env_cfg &c = p.cfg;
+    const double dt = c.time_step;
+    const bool lead = active && r == 0 && do_pair;       // writes the per-env outputs
+    const bool hlead = active && k == 0 && do_orca;      // writes the human's outputs
+
+    // ---- loads: own human, own candidate, robot (same-address loads across a quad / env coalesce) ----
+    const double2 pos = reinterpret_cast<const double2 *>(p.st.hpos)[a];
+    const double2 vel = reinterpret_cast<const double2 *>(p.st.hvel)[a];
+    const double2 goal = reinterpret_cast<const double2 *>(p.st.hgoal)[a];
+    const double rad = p.st.hrad[a];
+    const double vpref = p.st.hvpref[a];
+    const double2 rpos = reinterpret_cast<const double2 *>(p.st.rpos)[eb];
+    const double2 rgoal = reinterpret_cast<const double2 *>(p.st.rgoal)[eb];
+    const double2 act = reinterpret_cast<const double2 *>(p.actions)[eb];
+    const double rrad = p.st.rrad[eb];
+    const double gtime = p.st.gtime[eb];
+    double rtheta = 0;
+    if (c.robot_kinematics == MCN_KIN_UNICYCLE) rtheta = p.st.rtheta[eb];
+    const bool cand_h = k < NT - 1;                          // candidate is another human
+    const bool cand_r = VIS && (k == NT - 1);                // candidate is the robot
+    const int j = cand_h ? k + (k >= h ? 1 : 0) : h;
+    const long ca = eb * NT + j;
+    double2 cpos = reinterpret_cast<const double2 *>(p.st.hpos)[ca];
+    double2 cvel = reinterpret_cast<const double2 *>(p.st.hvel)[ca];
+    double crd = p.st.hrad[ca];
+    if (cand_r) {
+        cpos = rpos;
+        cvel = reinterpret_cast<const double2 *>(p.st.rvel)[eb];
+        crd = rrad;
+    }
+    int next_case = 0, ep_t = 0, ep_k = 0;
+    double ep_ret = 0, ep_disc = 0;
+    if (lead && p.has_roll) {
+        if (p.roll.next_case) next_case = p.roll.next_case[e];
+        if (p.roll.ep_return) {
+            ep_t = p.roll.ep_steps[e];
+            ep_ret = p.roll.ep_return[e];
+            ep_disc = p.roll.disc_table[ep_t < p.roll.disc_len ? ep_t : p.roll.disc_len - 1];
+            ep_k = p.roll.fin_count ? p.roll.fin_count[e] : 0;
+        }
+    }
+
+    // ---- K1: ORCA, one half-plane per lane ----
+    double hax = 0, hay = 0;
+    if (do_orca) {
+    const float fpx = (float)pos.x, fpy = (float)pos.y, fvx = (float)vel.x, fvy = (float)vel.y;
+    const float frad = (float)(rad + 0.01 + c.orca_safety_space);
+    const float ms = (float)vpref;
+    const float prefx = (float)(goal.x - pos.x), prefy = (float)(goal.y - pos.y);
+    const float4 o = make_float4((float)cpos.x, (float)cpos.y, (float)cvel.x, (float)cvel.y);
+    const float orad = (float)(crd + 0.01 + c.orca_safety_space);
+    const float range_sq = c.orca_neighbor_dist * c.orca_neighbor_dist;
+    const float ddx = fpx - o.x, ddy = fpy - o.y;
+    const float d = dot2(ddx, ddy, ddx, ddy);
+    const int in = ((cand_h || cand_r) && (d < range_sq)) ? 1 : 0;
+    const float d0 = qbf<0>(d), d1 = qbf<1>(d), d2 = qbf<2>(d), d3 = qbf<3>(d);
+    const int i0 = qbi<0>(in), i1 = qbi<1>(in), i2 = qbi<2>(in), i3 = qbi<3>(in);
+    const int nin = i0 + i1 + i2 + i3;
+    int rank;
+    if (in) {        // stable ascending order among the in-range candidates (RVO2 insertAgentNeighbor)
+        rank = (i0 && (d0 < d || (d0 == d && 0 < k))) + (i1 && (d1 < d || (d1 == d && 1 < k))) +
+               (i2 && (d2 < d || (d2 == d && 2 < k))) + (i3 && (d3 < d || (d3 == d && 3 < k)));
+    } else {         // the rest fill the remaining slots in lane order so that ranks stay a permutation
+        rank = nin + ((0 < k && !i0) ? 1 : 0) + ((1 < k && !i1) ? 1 : 0) + ((2 < k && !i2) ? 1 : 0);
+    }
+    int nl = nin < c.orca_max_neighbors ? nin : c.orca_max_neighbors;
+    const float inv_th = 1.0f / c.orca_time_horizon;
+    const float inv_ts = 1.0f / (float)dt;
+    const float4 mine = orca_line_merged(fpx, fpy, fvx, fvy, frad, o, orad, inv_th, inv_ts);
+    // route my half-plane to lane `rank` of the quad, then share all four
+    const int dst = ((lane & ~3) | rank) << 2;
+    float4 srt;
+    srt.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dst, __builtin_bit_cast(int, mine.x)));
+    srt.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dst, __builtin_bit_cast(int, mine.y)));
+    srt.z = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dst, __builtin_bit_cast(int, mine.z)));
+    srt.w = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dst, __builtin_bit_cast(int, mine.w)));
+    const float4 L[4] = {qb4<0>(srt), qb4<1>(srt), qb4<2>(srt), qb4<3>(srt)};
+
+    // speculative 1-D LPs, one per lane; then the incremental LP is four compare-and-take steps
+    float cx, cy;
+    const int okm = lp1_rt<false>(L, k, ms, prefx, prefy, cx, cy) ? 1 : 0;
+    float rx, ry;
+    if (dot2(prefx, prefy, prefx, prefy) > ms * ms) {
+        const float inv = 1.0f / sqrtf(dot2(prefx, prefy, prefx, prefy));
+        rx = ms * (prefx * inv); ry = ms * (prefy * inv);
+    } else {
+        rx = prefx; ry = prefy;
+    }
+    int fail = nl;
+#define MCN_LP2_TAKE(I)                                                                        \
+    {                                                                                          \
+        const int ok_i = qbi<I>(okm); const float cx_i = qbf<I>(cx), cy_i = qbf<I>(cy);        \
+        if (I < nl && fail == nl && det2(L[I].z, L[I].w, L[I].x - rx, L[I].y - ry) > 0.0f) {   \
+            if (ok_i) { rx = cx_i; ry = cy_i; } else fail = I;                                  \
+        }                                                                                      \
+    }
+    MCN_LP2_TAKE(0) MCN_LP2_TAKE(1) MCN_LP2_TAKE(2) MCN_LP2_TAKE(3)
+#undef MCN_LP2_TAKE
+    if (__any(fail < nl)) {
+        // dense crowd: 3-D LP.  Candidates of all four lines in parallel, combined in line order.
+        float c3x, c3y;
+        const int ok3 = lp3_candidate(L, k, ms, c3x, c3y) ? 1 : 0;
+        float dist = 0.0f;
+#define MCN_LP3_TAKE(I)                                                                        \
+    {                                                                                          \
+        const int ok_i = qbi<I>(ok3); const float cx_i = qbf<I>(c3x), cy_i = qbf<I>(c3y);      \
+        if (fail < nl && I >= fail && I < nl && det2(L[I].z, L[I].w, L[I].x - rx, L[I].y - ry) > dist) { \
+            if (ok_i) { rx = cx_i; ry = cy_i; }                                                 \
+            dist = det2(L[I].z, L[I].w, L[I].x - rx, L[I].y - ry);                             \
+        }                                                                                      \
+    }
+        MCN_LP3_TAKE(0) MCN_LP3_TAKE(1) MCN_LP3_TAKE(2) MCN_LP3_TAKE(3)
+#undef MCN_LP3_TAKE
+    }
+    hax = (double)rx; hay = (double)ry;
+    }
+
+    // ---- K2: swept circle on lane 0 of the quad, one human-human pair per lane ----
+    const int l0 = lane - r;
+    double rew = 0, dmin = INFINITY, endx = 0, endy = 0, new_theta = rtheta, nrvx = 0, nrvy = 0;
+    int dn = 0, inf = MCN_INFO_NOTHING;
+    const double t_new = gtime + dt;
+    if (do_pair) {
+    double2 eff = act;
+    if (c.robot_kinematics == MCN_KIN_UNICYCLE) {
+        eff.x = act.x * cos(act.y + rtheta);
+        eff.y = act.x * sin(act.y + rtheta);
+    }
+    double cd = INFINITY;
+    if (k == 0) {
+        const double px = pos.x - rpos.x, py = pos.y - rpos.y;
+        const double vx = vel.x - eff.x, vy = vel.y - eff.y;
+        cd = p2s_origin(px, py, px + vx * dt, py + vy * dt) - rad - rrad;
+    }
+    int hh = 0;
+    if (c.count_hh && cand_h && j > h) {        // each unordered pair exactly once (crowd_sim.py:369-374)
+        const double dx = pos.x - cpos.x, dy = pos.y - cpos.y;
+        hh = (sqrt(dx * dx + dy * dy) - rad - crd) < 0 ? 1 : 0;
+    }
+    cd = qbd<0>(cd);                                                    // the quad's swept distance
+    hh += __builtin_amdgcn_update_dpp(0, hh, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+    hh += __builtin_amdgcn_update_dpp(0, hh, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+    int hh_sum = 0;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        const int src = (l0 + 4 * q) & 63;
+        dmin = fmin(dmin, __shfl(cd, src));
+        hh_sum += __shfl(hh, src);
+    }
+
+    // ---- K3: ladder, recomputed by every lane of the env (cheap, avoids a broadcast) ----
+    if (c.robot_kinematics == MCN_KIN_UNICYCLE) {
+        const double th = rtheta + act.y;
+        endx = rpos.x + cos(th) * act.x * dt;
+        endy = rpos.y + sin(th) * act.x * dt;
+        new_theta = pymod(rtheta + act.y, 2 * M_PI);
+        nrvx = act.x * cos(new_theta); nrvy = act.x * sin(new_theta);
+    } else {
+        endx = rpos.x + act.x * dt; endy = rpos.y + act.y * dt;
+        nrvx = act.x; nrvy = act.y;
+    }
+    const bool reaching = norm2(endx - rgoal.x, endy - rgoal.y) < rrad;
+    if (gtime >= c.time_limit - 1)      { rew = 0; dn = 1; inf = MCN_INFO_TIMEOUT; }
+    else if (dmin < 0)                  { rew = c.collision_penalty; dn = 1; inf = MCN_INFO_COLLISION; }
+    else if (reaching)                  { rew = c.success_reward; dn = 1; inf = MCN_INFO_REACHGOAL; }
+    else if (dmin < c.discomfort_dist)  { rew = (dmin - c.discomfort_dist) * c.discomfort_penalty_factor * dt; dn = 0; inf = MCN_INFO_DANGER; }
+    else                                { rew = 0; dn = 0; inf = MCN_INFO_NOTHING; }
+    if (lead) {
+        p.out.reward[e] = rew;
+        p.out.dmin[e] = dmin;
+        p.out.done[e] = (uint8_t)dn;
+        p.out.info[e] = (uint8_t)inf;
+        p.out.hh_count[e] = hh_sum;
+    }
+    }   // do_pair
+    if (SPLIT) {
+        // hand-off: wavefront 1 publishes the done flag (and the reset case), wavefront 0 consumes them
+        if (lead) { s_dn[g] = dn; s_case[g] = next_case; }
+        __syncthreads();
+        if (role == 0) { dn = s_dn[g < 16 ? g : 0]; next_case = s_case[g < 16 ? g : 0]; }
+    }
+    if (hlead && p.out.human_act) reinterpret_cast<double2 *>(p.out.human_act)[a] = make_double2(hax, hay);
+
+    // ---- integrate / look ahead ----
+    const double npx = pos.x + hax * dt, npy = pos.y + hay * dt;
+    if (!p.update) {
+        if (hlead) {
+            reinterpret_cast<double2 *>(p.out.nobs_pos)[a] = make_double2(npx, npy);
+            reinterpret_cast<double2 *>(p.out.nobs_vel)[a] = make_double2(hax, hay);
+        }
+        return;
+    }
+    const bool do_reset = p.has_roll && p.roll.pool_hpos != nullptr;
+    const int case_g = SPLIT ? next_case : __shfl(next_case, l0 & 63);
+    if (hlead) {
+        if (do_reset && dn) {
+            const long pa = (long)case_g * NT + h;
+            reinterpret_cast<double2 *>(p.st.hpos)[a]  = reinterpret_cast<const double2 *>(p.roll.pool_hpos)[pa];
+            reinterpret_cast<double2 *>(p.st.hgoal)[a] = reinterpret_cast<const double2 *>(p.roll.pool_hgoal)[pa];
+            p.st.hrad[a] = p.roll.pool_hrad[pa];
+            p.st.hvpref[a] = p.roll.pool_hvpref[pa];
+            reinterpret_cast<double2 *>(p.st.hvel)[a]  = p.roll.pool_hvel
+                ? reinterpret_cast<const double2 *>(p.roll.pool_hvel)[pa] : make_double2(0, 0);
+            if (p.st.human_times) p.st.human_times[a] = 0;
+        } else {
+            reinterpret_cast<double2 *>(p.st.hpos)[a] = make_double2(npx, npy);
+            reinterpret_cast<double2 *>(p.st.hvel)[a] = make_double2(hax, hay);
+            if (c.track_human_times && p.st.human_times) {
+                if (p.st.human_times[a] == 0 && norm2(npx - goal.x, npy - goal.y) < rad)
+                    p.st.human_times[a] = t_new;
+            }
+        }
+    }
+    if (lead) {
+        if (p.has_roll) {
+            const mcn_rollout &ro = p.roll;
+            if (inf == MCN_INFO_DANGER && ro.danger_count) {
+                ro.danger_count[e] += 1;
+                if (ro.danger_dist_sum) ro.danger_dist_sum[e] += dmin;
+            }
+            if (ro.ep_return) {
+                const double ret = ep_ret + ep_disc * rew;
+                if (dn) {
+                    const bool keep = (ro.fin_slots == 1) || (ep_k < ro.fin_slots);
+                    const long rec = (long)(ro.fin_slots == 1 ? 0 : ep_k) * p.E + e;
+                    if (keep && ro.fin_return) ro.fin_return[rec] = ret;
+                    if (keep && ro.fin_time)   ro.fin_time[rec] = (inf == MCN_INFO_TIMEOUT) ? c.time_limit : t_new;
+                    if (keep && ro.fin_info)   ro.fin_info[rec] = (uint8_t)inf;
+                    if (ro.fin_count)  ro.fin_count[e] = ep_k + 1;
+                    ro.ep_return[e] = 0; ro.ep_steps[e] = 0;
+                } else {
+                    ro.ep_return[e] = ret; ro.ep_steps[e] = ep_t + 1;
+                }
+            }
+        }
+        if (do_reset && dn) {
+            reinterpret_cast<double2 *>(p.st.rpos)[e]  = make_double2(p.roll.robot_start[0], p.roll.robot_start[1]);
+            reinterpret_cast<double2 *>(p.st.rgoal)[e] = make_double2(p.roll.robot_goal[0], p.roll.robot_goal[1]);
+            reinterpret_cast<double2 *>(p.st.rvel)[e]  = make_double2(0, 0);
+            if (p.st.rtheta) p.st.rtheta[e] = p.roll.robot_theta0;
+            p.st.gtime[e] = 0;
+            if (p.roll.next_case) p.roll.next_case[e] = (next_case + p.roll.case_stride) % p.roll.pool_size;
+        } else {
+            reinterpret_cast<double2 *>(p.st.rpos)[e] = make_double2(endx, endy);
+            reinterpret_cast<double2 *>(p.st.rvel)[e] = make_double2(nrvx, nrvy);
+            if (c.robot_kinematics == MCN_KIN_UNICYCLE) p.st.rtheta[e] = new_theta;
+            p.st.gtime[e] = t_new;
+        }
+    }
+}
+
+template <int NT, int VIS>
+static void launch_quad_one(const StepParams &p, hipStream_t stream)
+{
+    constexpr int G = 64 / (4 * NT);
+    const int blocks = (p.E + G - 1) / G;
+    if (p.quad_split)
+        hipLaunchKernelGGL((env_step_quad_kernel<NT, VIS, true>), dim3(blocks), dim3(128), 0, stream, p);
+    else
+        hipLaunchKernelGGL((env_step_quad_kernel<NT, VIS, false>), dim3(blocks), dim3(64), 0, stream, p);
+}
+
+// Returns true when the quad kernel handles this problem (ORCA humans, <= 4 neighbours each).
+bool launch_env_step_quad(const StepParams &p, hipStream_t stream)
+{
+    if (p.cfg.human_policy != MCN_HUMANS_ORCA || p.cfg.orca_max_neighbors < 4) return false;
+    const int vis = p.cfg.robot_visible ? 1 : 0;
+    const int nc = p.N - 1 + vis;
+    if (nc > 4 || p.N < 1) return false;
+    switch (p.N * 2 + vis) {
+        case 2:  launch_quad_one<1, 0>(p, stream); break;
+        case 3:  launch_quad_one<1, 1>(p, stream); break;
+        case 4:  launch_quad_one<2, 0>(p, stream); break;
+        case 5:  launch_quad_one<2, 1>(p, stream); break;
+        case 6:  launch_quad_one<3, 0>(p, stream); break;
+        case 7:  launch_quad_one<3, 1>(p, stream); break;
+        case 8:  launch_quad_one<4, 0>(p, stream); break;
+        case 9:  launch_quad_one<4, 1>(p, stream); break;
+        case 10: launch_quad_one<5, 0>(p, stream); break;
+        default: return false;
+    }
+    return true;
+}
+
+}  // namespace mcn

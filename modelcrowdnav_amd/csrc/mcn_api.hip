@@ -3,6 +3,7 @@
 // is never started on shapes its indexing does not assume.
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <stdlib.h>
 #include "../../include/mcn.h"
 
 #include "env_step_params.hpp"
@@ -56,6 +57,19 @@ int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *
     int nl = ncand < cfg->orca_max_neighbors ? ncand : cfg->orca_max_neighbors;
     if (cfg->human_policy != MCN_HUMANS_ORCA) nl = 0;
     p.nl_cap = nl;
+    {
+        // Small batches are latency-bound: use the quad-parallel kernel (env_step_quad.hip) while its 4x wider
+        // grid still fits the chip about twice over (measured cross-over on MI355X: ~2800 wavefronts, i.e.
+        // E <= 8192 at 5 humans); above that the lane-per-human kernel wins on throughput.  Inside the quad
+        // kernel, ORCA and the float64 pairwise work go to two cooperating wavefronts only while BOTH still get a
+        // SIMD of their own (grid <= 512 workgroups).  MCN_QUAD_MAX_ENVS / MCN_QUAD_SPLIT override (tests, tuning).
+        static const char *env_max = getenv("MCN_QUAD_MAX_ENVS");
+        static const char *env_split = getenv("MCN_QUAD_SPLIT");
+        const int envs_per_wave = 64 / (4 * N);
+        const long quad_waves = envs_per_wave > 0 ? ((long)E + envs_per_wave - 1) / envs_per_wave : (1L << 40);
+        p.quad_max_envs = env_max ? atoi(env_max) : (quad_waves <= 2800 ? E : 0);
+        p.quad_split = env_split ? atoi(env_split) : (quad_waves <= 512 ? 1 : 0);
+    }
     return mcn::launch_env_step(p, (hipStream_t)stream);
 }
 

@@ -16,6 +16,45 @@
 
 namespace mcn {
 
+// Half-plane induced by one neighbour.  The cut-off-circle case and the already-colliding case differ only in
+// the inverse time constant (1/timeHorizon vs 1/timeStep), so they share one code path.
+__device__ __forceinline__ float4 orca_line_merged(float px, float py, float vx, float vy, float radius, float4 o,
+                                                   float orad, float inv_th, float inv_ts)
+{
+        const float rpx = o.x - px, rpy = o.y - py;
+    const float rvx = vx - o.z, rvy = vy - o.w;
+    const float dist_sq = dot2(rpx, rpy, rpx, rpy);
+    const float cr = radius + orad;
+    const float cr_sq = cr * cr;
+    const bool apart = dist_sq > cr_sq;
+    const float inv = apart ? inv_th : inv_ts;          // collision case uses 1/timeStep
+    const float wx = rvx - inv * rpx, wy = rvy - inv * rpy;
+    const float wl_sq = dot2(wx, wy, wx, wy);
+    const float dp1 = dot2(wx, wy, rpx, rpy);
+    float dx, dy, ux, uy;
+    if (!apart || (dp1 < 0.0f && dp1 * dp1 > cr_sq * wl_sq)) {
+        const float wl = sqrtf(wl_sq);
+        const float iw = 1.0f / wl;
+        const float uwx = wx * iw, uwy = wy * iw;
+        dx = uwy; dy = -uwx;
+        const float s = cr * inv - wl;
+        ux = s * uwx; uy = s * uwy;
+    } else {
+        const float leg = sqrtf(dist_sq - cr_sq);
+        const float id = 1.0f / dist_sq;
+        if (det2(rpx, rpy, wx, wy) > 0.0f) {
+            dx = (rpx * leg - rpy * cr) * id;
+            dy = (rpx * cr + rpy * leg) * id;
+        } else {
+            dx = -((rpx * leg + rpy * cr) * id);
+            dy = -((-rpx * cr + rpy * leg) * id);
+        }
+        const float dp2 = dot2(rvx, rvy, dx, dy);
+        ux = dp2 * dx - rvx; uy = dp2 * dy - rvy;
+    }
+    return make_float4(vx + 0.5f * ux, vy + 0.5f * uy, dx, dy);
+}
+
 // 1-D LP on line NO (compile-time) against lines [0, NO).  DIR = false: closest point to (optx,opty);
 // DIR = true: farthest point along the unit direction (optx,opty) (used by the 3-D LP).
 template <int NO, int NL, bool DIR = false>
@@ -171,39 +210,7 @@ __device__ __forceinline__ void orca_solve_static(float4 (&cpv)[NC > 0 ? NC : 1]
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
         if (k < NC) {
-            const float4 o = cpv[k];
-            const float rpx = o.x - px, rpy = o.y - py;
-            const float rvx = vx - o.z, rvy = vy - o.w;
-            const float dist_sq = dot2(rpx, rpy, rpx, rpy);
-            const float cr = radius + crad[k];
-            const float cr_sq = cr * cr;
-            const bool apart = dist_sq > cr_sq;
-            const float inv = apart ? inv_th : inv_ts;          // collision case uses 1/timeStep
-            const float wx = rvx - inv * rpx, wy = rvy - inv * rpy;
-            const float wl_sq = dot2(wx, wy, wx, wy);
-            const float dp1 = dot2(wx, wy, rpx, rpy);
-            float dx, dy, ux, uy;
-            if (!apart || (dp1 < 0.0f && dp1 * dp1 > cr_sq * wl_sq)) {
-                const float wl = sqrtf(wl_sq);
-                const float iw = 1.0f / wl;
-                const float uwx = wx * iw, uwy = wy * iw;
-                dx = uwy; dy = -uwx;
-                const float s = cr * inv - wl;
-                ux = s * uwx; uy = s * uwy;
-            } else {
-                const float leg = sqrtf(dist_sq - cr_sq);
-                const float id = 1.0f / dist_sq;
-                if (det2(rpx, rpy, wx, wy) > 0.0f) {
-                    dx = (rpx * leg - rpy * cr) * id;
-                    dy = (rpx * cr + rpy * leg) * id;
-                } else {
-                    dx = -((rpx * leg + rpy * cr) * id);
-                    dy = -((-rpx * cr + rpy * leg) * id);
-                }
-                const float dp2 = dot2(rvx, rvy, dx, dy);
-                ux = dp2 * dx - rvx; uy = dp2 * dy - rvy;
-            }
-            L[k] = make_float4(vx + 0.5f * ux, vy + 0.5f * uy, dx, dy);
+            L[k] = orca_line_merged(px, py, vx, vy, radius, cpv[k], crad[k], inv_th, inv_ts);
         } else {
             L[k] = make_float4(0, 0, 1, 0);
         }

@@ -63,8 +63,8 @@ int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *
         // E <= 8192 at 5 humans); above that the lane-per-human kernel wins on throughput.  Inside the quad
         // kernel, ORCA and the float64 pairwise work go to two cooperating wavefronts only while BOTH still get a
         // SIMD of their own (grid <= 512 workgroups).  MCN_QUAD_MAX_ENVS / MCN_QUAD_SPLIT override (tests, tuning).
-        static const char *env_max = getenv("MCN_QUAD_MAX_ENVS");
-        static const char *env_split = getenv("MCN_QUAD_SPLIT");
+        const char *env_max = getenv("MCN_QUAD_MAX_ENVS");
+        const char *env_split = getenv("MCN_QUAD_SPLIT");
         const int envs_per_wave = 64 / (4 * N);
         const long quad_waves = envs_per_wave > 0 ? ((long)E + envs_per_wave - 1) / envs_per_wave : (1L << 40);
         p.quad_max_envs = env_max ? atoi(env_max) : (quad_waves <= 2800 ? E : 0);

@@ -46,7 +46,17 @@ def _step_both(env, st, ax, ay, update, policy=cport.HUMANS_ORCA, given=None):
                                                  (7, False, True), (9, True, False), (13, False, True),
                                                  (32, False, False)])
 @pytest.mark.parametrize("update", [True, False])
-def test_step_matches_oracle_bitexact(N, visible, randomize, update):
+@pytest.mark.parametrize("kernel", ["auto", "lane-per-human", "quad", "quad-split"])
+def test_step_matches_oracle_bitexact(N, visible, randomize, update, kernel, monkeypatch):
+    # the same arithmetic exists in three decompositions (env_step.hip, env_step_quad.hip +- wavefront split);
+    # MCN_QUAD_* pin which one the dispatcher picks
+    if kernel == "lane-per-human":
+        monkeypatch.setenv("MCN_QUAD_MAX_ENVS", "0")
+    elif kernel.startswith("quad"):
+        if N - 1 + int(visible) > 4:
+            pytest.skip("quad kernel handles at most 4 neighbours")
+        monkeypatch.setenv("MCN_QUAD_MAX_ENVS", str(1 << 30))
+        monkeypatch.setenv("MCN_QUAD_SPLIT", "1" if kernel == "quad-split" else "0")
     rng = np.random.RandomState(100 + N + 7 * visible)
     E = 777   # ragged: not a multiple of the envs-per-wave count
     env = H.make_vec_env(E, N, robot_visible=visible)
@@ -129,7 +139,14 @@ def test_step_matches_reference_fixtures(name, policy, golden_dir):
                     np.testing.assert_allclose(env.human_times.cpu().numpy(), g["human_times"][sel][:, :N], rtol=0, atol=0)
 
 
-def test_rollout_4096x5_bitexact_trajectory():
+@pytest.mark.parametrize("kernel", ["auto", "lane-per-human"])
+def test_rollout_4096x5_bitexact_trajectory(kernel, monkeypatch):
+    if kernel == "lane-per-human":
+        monkeypatch.setenv("MCN_QUAD_MAX_ENVS", "0")
+    _rollout_4096x5()
+
+
+def _rollout_4096x5():
     """BASELINE config 2 shape: 4096 envs x 5 humans, ORCA humans, random robot actions, 60 steps.
     Whole trajectories must stay bit-identical to the oracle (any 1-ulp slip would compound)."""
     torch = _torch()

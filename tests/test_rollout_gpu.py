@@ -255,3 +255,57 @@ def test_update_memory_value_targets(il):
     assert torch.equal(got_s, torch.stack(want_s))
     if il:
         assert (rec["infos"].cpu().numpy()[rec["dones"].cpu().numpy()] == 2).sum() > 0, "ORCA robot should reach goals"
+
+
+def test_reference_driver_sequence_through_dropin():
+    """The call sequence of crowd_nav/test.py:52-109 and train.py:120-160 with the reference's own import paths
+    (after dropin.install()): gym.make, configure, Robot, policy_factory, Explorer.run_k_episodes, imitation-
+    learning memory fill.  The sequential Explorer (E = 1 env) and the batched VecExplorer must report the same
+    episodes."""
+    import torch
+    import modelcrowdnav_amd.dropin as dropin
+    dropin.install()
+    import gym
+    from crowd_nav.policy.policy_factory import policy_factory
+    from crowd_nav.utils.explorer import Explorer
+    from crowd_nav.utils.memory import ReplayMemory
+    from crowd_sim.envs.utils.robot import Robot
+    from crowd_sim.envs.policy.orca import ORCA
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.rollout import VecExplorer
+    device = torch.device("cuda:0")
+    env_config = configs.env_config()
+    policy = policy_factory["orca"]()
+    policy.configure(env_config)
+    env = gym.make("CrowdSim-v0")
+    env.configure(env_config)
+    robot = Robot(env_config, "robot")
+    robot.set_policy(policy)
+    env.set_robot(robot)
+    sarl = policy_factory["sarl"]()
+    sarl.configure(configs.policy_config()); sarl.kinematics = "holonomic"; sarl.set_device(device)
+    memory = ReplayMemory(5000)
+    explorer = Explorer(env, robot, device, memory, gamma=0.9, target_policy=sarl)
+    policy.set_phase("test"); policy.set_device(device); policy.set_env(env)
+    assert isinstance(robot.policy, ORCA)
+    robot.policy.safety_space = 0
+    k = 4
+    avg, sr, cr, tr = explorer.run_k_episodes(k, "test", update_memory=True, imitation_learning=True, print_failure=True)
+    assert abs(sr + cr + tr - 1) < 1e-12 and len(memory) > 0
+    assert env.case_counter["test"] == k
+    state, value = memory[0]
+    assert tuple(state.shape) == (5, 13) and tuple(value.shape) == (1,)
+    # the same four cases, batched
+    venv = H.make_vec_env(k, 5)
+    venv.track_human_times = False; venv.export_human_actions = False
+    orca = policy_factory["orca"](); orca.multiagent_training = True; orca.safety_space = 0
+    venv.robot.set_policy(orca)
+    vmem = ReplayMemory(5000, device=device)
+    vex = VecExplorer(venv, venv.robot, gamma=0.9, policy=orca, memory=vmem, target_policy=sarl)
+    vavg, vsr, vcr, vtr = vex.run_k_episodes(k, "test", update_memory=True, imitation_learning=True)
+    assert (vsr, vcr, vtr) == (sr, cr, tr)
+    assert abs(vavg - avg) < 1e-12
+    assert len(vmem) == len(memory)
+    got = sorted(float(vmem[i][1]) for i in range(len(vmem)))
+    want = sorted(float(memory[i][1]) for i in range(len(memory)))
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)

@@ -118,11 +118,29 @@ def pairwise_bytes_per_env_step(N):
     return (15 + 11 * N) * 8 + 6
 
 
+_PMC = None
+
+
+def pmc_traffic(E, given):
+    """HBM bytes per launch from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    passes, gfx950 FETCH_SIZE x2 correction; profiles/r01_pmc_env_step.json).  None where no such run exists."""
+    global _PMC
+    if _PMC is None:
+        try:
+            _PMC = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_env_step.json")))["kernels"]
+        except Exception:
+            _PMC = []
+    for k in _PMC:
+        if k["envs"] == E and ("pairwise-only" in k["what"]) == bool(given):
+            return k["traffic_bytes_per_launch"]
+    return None
+
+
 def roofline_entry(E, N, avg_ms, extra=None, given=False):
     by = (pairwise_bytes_per_env_step(N) if given else algorithmic_bytes_per_env_step(N)) * E
     ach = by / (avg_ms * 1e-3) / 1e9
     d = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(E, given) if N == 5 else None,
          "kernel": "mcn::env_step_kernel", "envs_per_launch": E, "algorithmic_bytes_per_launch": by,
          "avg_launch_us": round(avg_ms * 1e3, 3)}
     if extra:

@@ -152,11 +152,15 @@ int mcn_orca_batch(const float *self, const float *others, const int32_t *n_othe
 /*
  * mcn_pack_linear -- HOST helper: permute one nn.Linear (weight [nout][kin] row-major, bias [nout])
  * into the MFMA operand order the network kernels stream (see mfma_chain.hpp; used for SARL and SGAN).  kmap[t*16 + s] is the column of
- * `weight` that input slot s of input tile t carries, or -1 for padding; KT input tiles.
- * wfrag_out: [ceil(nout/16)][KT][64][4] floats, bfrag_out: [ceil(nout/16)][64][4] floats (may be NULL).
+ * `weight` that input slot s of input tile t carries, or -1 for padding; KT input tiles.  omap[n*16 + s] is the
+ * row of `weight` produced in output slot s of output tile n, or -1 (NULL = identity: row 16n + s); NT output
+ * tiles.  Slot s = 4q + r lives in accumulator register r of lane group q, so a ragged last tile packed
+ * "q first" (feature j at slot 4(j%4) + j/4) needs only ceil(w/4) k-steps in the layer that consumes it.
+ * wfrag_out: [NT][KT][64][4] floats, bfrag_out: [NT][64][4] floats (may be NULL).
  */
 int mcn_pack_linear(const float *weight, const float *bias, int32_t nout, int32_t kin,
-                        const int32_t *kmap, int32_t KT, float *wfrag_out, float *bfrag_out);
+                    const int32_t *kmap, int32_t KT, const int32_t *omap, int32_t NT,
+                    float *wfrag_out, float *bfrag_out);
 
 /* Device pointers to the packed fragments of one ValueNetwork (state_dict keys in comments). */
 typedef struct mcn_sarl_net {

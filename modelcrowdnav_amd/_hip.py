@@ -69,7 +69,7 @@ def _load():
     lib.mcn_orca_batch.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _f, _f, _vp]
     lib.mcn_orca_batch.restype = C.c_int
     fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
-    lib.mcn_pack_linear.argtypes = [fp, fp, _i, _i, ip, _i, fp, fp]
+    lib.mcn_pack_linear.argtypes = [fp, fp, _i, _i, ip, _i, ip, _i, fp, fp]
     lib.mcn_pack_linear.restype = C.c_int
     lib.mcn_sarl_workspace_bytes.argtypes = [_i, _i, _i]
     lib.mcn_sarl_workspace_bytes.restype = C.c_int64

@@ -86,18 +86,23 @@ int mcn_orca_batch(const float *self, const float *others, const int32_t *n_othe
 }
 
 int mcn_pack_linear(const float *weight, const float *bias, int32_t nout, int32_t kin,
-                        const int32_t *kmap, int32_t KT, float *wfrag_out, float *bfrag_out)
+                    const int32_t *kmap, int32_t KT, const int32_t *omap, int32_t NT,
+                    float *wfrag_out, float *bfrag_out)
 {
-    if (!weight || !kmap || !wfrag_out || nout <= 0 || kin <= 0 || KT <= 0) return MCN_EINVAL;
-    const int NT = (nout + 15) / 16;
+    if (!weight || !kmap || !wfrag_out || nout <= 0 || kin <= 0 || KT <= 0 || NT <= 0) return MCN_EINVAL;
+    if (!omap && NT != (nout + 15) / 16) return MCN_EINVAL;
+    auto orow = [&](int n, int slot) { return omap ? omap[n * 16 + slot] : 16 * n + slot; };
+    for (int n = 0; n < NT; ++n)
+        for (int slot = 0; slot < 16; ++slot)
+            if (orow(n, slot) >= nout) { if (omap) return MCN_EINVAL; }
     for (int n = 0; n < NT; ++n)
         for (int t = 0; t < KT; ++t)
             for (int lane = 0; lane < 64; ++lane)
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * n + (lane & 15);
+                    const int row = orow(n, lane & 15);
                     const int col = kmap[t * 16 + 4 * (lane >> 4) + r];
                     float v = 0.0f;
-                    if (row < nout && col >= 0) {
+                    if (row >= 0 && row < nout && col >= 0) {
                         if (col >= kin) return MCN_EINVAL;
                         v = weight[(size_t)row * kin + col];
                     }
@@ -107,8 +112,8 @@ int mcn_pack_linear(const float *weight, const float *bias, int32_t nout, int32_
         for (int n = 0; n < NT; ++n)
             for (int lane = 0; lane < 64; ++lane)
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * n + 4 * (lane >> 4) + r;
-                    bfrag_out[((size_t)n * 64 + lane) * 4 + r] = (bias && row < nout) ? bias[row] : 0.0f;
+                    const int row = orow(n, 4 * (lane >> 4) + r);
+                    bfrag_out[((size_t)n * 64 + lane) * 4 + r] = (bias && row >= 0 && row < nout) ? bias[row] : 0.0f;
                 }
     return MCN_OK;
 }

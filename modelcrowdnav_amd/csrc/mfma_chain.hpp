@@ -91,21 +91,24 @@ __device__ __forceinline__ void dense_acc(const f32x4 (&in)[KT], const f32x4 (&i
 // multiplied, the loads of chunk c+1 are already in flight (issued before the MFMAs, written to the other
 // buffer after them); one barrier per chunk.  Every thread of the workgroup must call this uniformly.
 constexpr int kStageThreads = 512;
-constexpr int kStageFloat4 = 2 * 10 * 64;        // largest chunk: 2 output tiles x KT = 10 input tiles
+constexpr int kChunkTiles = 4;                                   // output tiles per staged chunk
+constexpr int kStageFloat4 = kChunkTiles * 10 * 64;              // largest chunk: 4 output tiles x KT = 10 input tiles
 
 struct WeightStage {
     float4 *buf;      // LDS, 2 * kStageFloat4 float4
     int tid;          // threadIdx.x, 0 .. kStageThreads-1
 };
 
-template <int KT, int NT, bool RELU, bool HAS_INIT>
+// LAST / LAST2: k-steps actually needed in the last / second-to-last input tile (ragged tiles packed "q first",
+// see mcn_pack_linear): the skipped steps would multiply zeros.
+template <int KT, int NT, bool RELU, bool HAS_INIT, int LAST = 4, int LAST2 = 4>
 __device__ __forceinline__ void dense_staged(const f32x4 (&in)[KT], const f32x4 *init, f32x4 (&out)[NT],
                                              const float4 *__restrict__ wf, const float4 *__restrict__ bf,
                                              const WeightStage &S, int lane)
 {
-    constexpr int CH = 2 * KT * 64;                       // float4 per full chunk
+    constexpr int CH = kChunkTiles * KT * 64;             // float4 per full chunk
     constexpr int TOTAL = NT * KT * 64;
-    constexpr int NCH = (NT + 1) / 2;
+    constexpr int NCH = (NT + kChunkTiles - 1) / kChunkTiles;
     constexpr int PER = (CH + kStageThreads - 1) / kStageThreads;
     float4 pre[PER];
     auto gload = [&](int c) {
@@ -127,38 +130,51 @@ __device__ __forceinline__ void dense_staged(const f32x4 (&in)[KT], const f32x4 
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int n = 2 * c;
-        const bool two = (n + 1 < NT);
         if (c + 1 < NCH) gload(c + 1);
-        const float4 *w = S.buf + (c & 1) * kStageFloat4;
-        f32x4 a0, a1 = {0, 0, 0, 0};
-        if (HAS_INIT) {
-            a0 = init[n];
-            if (two) a1 = init[n + 1];
-        } else {
-            { const float4 b = bf[n * 64 + lane]; a0 = (f32x4){b.x, b.y, b.z, b.w}; }
-            if (two) { const float4 b = bf[(n + 1) * 64 + lane]; a1 = (f32x4){b.x, b.y, b.z, b.w}; }
-        }
+        const float4 *wc = S.buf + (c & 1) * kStageFloat4;
 #pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            const float4 w0 = w[t * 64 + lane];
-            float4 w1 = make_float4(0, 0, 0, 0);
-            if (two) w1 = w[(KT + t) * 64 + lane];
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, in[t][0], a0, 0, 0, 0);
-            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, in[t][0], a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, in[t][1], a0, 0, 0, 0);
-            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, in[t][1], a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, in[t][2], a0, 0, 0, 0);
-            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, in[t][2], a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, in[t][3], a0, 0, 0, 0);
-            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, in[t][3], a1, 0, 0, 0);
-        }
-        if (RELU) {
+        for (int h2 = 0; h2 < kChunkTiles; h2 += 2) {
+            const int n = kChunkTiles * c + h2;
+            if (n < NT) {
+                const bool two = (n + 1 < NT);
+                const float4 *w = wc + h2 * KT * 64;
+                f32x4 a0, a1 = {0, 0, 0, 0};
+                if (HAS_INIT) {
+                    a0 = init[n];
+                    if (two) a1 = init[n + 1];
+                } else {
+                    { const float4 b = bf[n * 64 + lane]; a0 = (f32x4){b.x, b.y, b.z, b.w}; }
+                    if (two) { const float4 b = bf[(n + 1) * 64 + lane]; a1 = (f32x4){b.x, b.y, b.z, b.w}; }
+                }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { a0[r] = fmaxf(a0[r], 0.0f); a1[r] = fmaxf(a1[r], 0.0f); }
+                for (int t = 0; t < KT; ++t) {
+                    const float4 w0 = w[t * 64 + lane];
+                    float4 w1 = make_float4(0, 0, 0, 0);
+                    if (two) w1 = w[(KT + t) * 64 + lane];
+                    const int steps = (t == KT - 1) ? LAST : ((t == KT - 2) ? LAST2 : 4);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, in[t][0], a0, 0, 0, 0);
+                    if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, in[t][0], a1, 0, 0, 0);
+                    if (steps > 1) {
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, in[t][1], a0, 0, 0, 0);
+                        if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, in[t][1], a1, 0, 0, 0);
+                    }
+                    if (steps > 2) {
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, in[t][2], a0, 0, 0, 0);
+                        if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, in[t][2], a1, 0, 0, 0);
+                    }
+                    if (steps > 3) {
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, in[t][3], a0, 0, 0, 0);
+                        if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, in[t][3], a1, 0, 0, 0);
+                    }
+                }
+                if (RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { a0[r] = fmaxf(a0[r], 0.0f); a1[r] = fmaxf(a1[r], 0.0f); }
+                }
+                out[n] = a0;
+                if (two) out[n + 1] = a1;
+            }
         }
-        out[n] = a0;
-        if (two) out[n + 1] = a1;
         if (c + 1 < NCH) lstore((c + 1) & 1);
         __syncthreads();
     }

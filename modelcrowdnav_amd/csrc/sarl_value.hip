@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, 2) void sarl_value_kernel(const Sa
         f32x4 h1[T150];
         dense_staged<T13, T150, true, false>(x, nullptr, h1, p.f.w_m1a, p.f.b_m1a, S, lane);
         f32x4 h2[T100];
-        dense_staged<T150, T100, true, false>(h1, nullptr, h2, p.f.w_m1b, p.f.b_m1b, S, lane);
+        dense_staged<T150, T100, true, false, 2>(h1, nullptr, h2, p.f.w_m1b, p.f.b_m1b, S, lane);
 #pragma unroll
         for (int t = 0; t < T100; ++t) {
             ws[(i * T100 + t) * 64 + lane] = make_float4(h2[t][0], h2[t][1], h2[t][2], h2[t][3]);
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, 2) void sarl_value_kernel(const Sa
 #pragma unroll
         for (int r = 0; r < 4; ++r) gsum[t][r] = gsum[t][r] / fn;
     f32x4 gat[T100];
-    dense_staged<T100, T100, false, false>(gsum, nullptr, gat, p.f.w_atg, p.f.b_ata, S, lane);
+    dense_staged<T100, T100, false, false, 1>(gsum, nullptr, gat, p.f.w_atg, p.f.b_ata, S, lane);
 
     // ---- pass 2: attention score, mlp2, pooling ----
     f32x4 pooled[T50];
@@ -191,20 +191,20 @@ __global__ __launch_bounds__(kSarlWaves * 64, 2) void sarl_value_kernel(const Sa
             h2[t] = (f32x4){v.x, v.y, v.z, v.w};
         }
         f32x4 a1[T100];
-        dense_staged<T100, T100, true, true>(h2, gat, a1, p.f.w_ata, nullptr, S, lane);
+        dense_staged<T100, T100, true, true, 1>(h2, gat, a1, p.f.w_ata, nullptr, S, lane);
         f32x4 a2[T100];
-        dense_staged<T100, T100, true, false>(a1, nullptr, a2, p.f.w_atb, p.f.b_atb, S, lane);
+        dense_staged<T100, T100, true, false, 1>(a1, nullptr, a2, p.f.w_atb, p.f.b_atb, S, lane);
         f32x4 sc[T1];
-        dense_staged<T100, T1, false, false>(a2, nullptr, sc, p.f.w_atc, p.f.b_atc, S, lane);
+        dense_staged<T100, T1, false, false, 1>(a2, nullptr, sc, p.f.w_atc, p.f.b_atc, S, lane);
         // score of pair j sits in lane j (q = 0), register 0; broadcast to the pair's four lanes
         const float s = __shfl(sc[0][0], j);
         const float es = (s != 0.0f) ? expf(s) : 0.0f;          // exp(s) * (s != 0), sarl.py:52
         if (p.attention && valid && q == 0) p.attention[pair * N + i] = es;   // normalised by the host view
         denom += es;
         f32x4 m1[T100];
-        dense_staged<T100, T100, true, false>(h2, nullptr, m1, p.f.w_m2a, p.f.b_m2a, S, lane);
+        dense_staged<T100, T100, true, false, 1>(h2, nullptr, m1, p.f.w_m2a, p.f.b_m2a, S, lane);
         f32x4 m2[T50];
-        dense_staged<T100, T50, false, false>(m1, nullptr, m2, p.f.w_m2b, p.f.b_m2b, S, lane);
+        dense_staged<T100, T50, false, false, 1>(m1, nullptr, m2, p.f.w_m2b, p.f.b_m2b, S, lane);
 #pragma unroll
         for (int t = 0; t < T50; ++t)
 #pragma unroll
@@ -218,18 +218,19 @@ __global__ __launch_bounds__(kSarlWaves * 64, 2) void sarl_value_kernel(const Sa
 #pragma unroll
         for (int r = 0; r < 4; ++r) jin[t][r] = pooled[t][r] / denom;
     {
-        const float self6[8] = {dg, svpref, f_theta, srad, f_vx, f_vy, 0.0f, 0.0f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) jin[T50][r] = q == 0 ? self6[r] : (q == 1 ? self6[4 + r] : 0.0f);
+        // the 6 self features, packed "q first": feature j sits in register j/4 of lane group j%4 (two k-steps)
+        const float s0 = q == 0 ? dg : (q == 1 ? svpref : (q == 2 ? f_theta : srad));
+        const float s1 = q == 0 ? f_vx : (q == 1 ? f_vy : 0.0f);
+        jin[T50] = (f32x4){s0, s1, 0.0f, 0.0f};
     }
     f32x4 v1[T150];
-    dense_staged<T56, T150, true, false>(jin, nullptr, v1, p.f.w_m3a, p.f.b_m3a, S, lane);
+    dense_staged<T56, T150, true, false, 2, 1>(jin, nullptr, v1, p.f.w_m3a, p.f.b_m3a, S, lane);
     f32x4 v2[T100];
-    dense_staged<T150, T100, true, false>(v1, nullptr, v2, p.f.w_m3b, p.f.b_m3b, S, lane);
+    dense_staged<T150, T100, true, false, 2>(v1, nullptr, v2, p.f.w_m3b, p.f.b_m3b, S, lane);
     f32x4 v3[T100];
-    dense_staged<T100, T100, true, false>(v2, nullptr, v3, p.f.w_m3c, p.f.b_m3c, S, lane);
+    dense_staged<T100, T100, true, false, 1>(v2, nullptr, v3, p.f.w_m3c, p.f.b_m3c, S, lane);
     f32x4 vo[T1];
-    dense_staged<T100, T1, false, false>(v3, nullptr, vo, p.f.w_m3d, p.f.b_m3d, S, lane);
+    dense_staged<T100, T1, false, false, 1>(v3, nullptr, vo, p.f.w_m3d, p.f.b_m3d, S, lane);
     if (valid && q == 0) {
         // value = reward + gamma^(dt * v_pref) * V   (multi_human_rl.py:52, Python float arithmetic)
         p.values[pair] = reward + p.gamma_pow * (double)vo[0][0];

@@ -52,6 +52,19 @@ class ValueNetwork(nn.Module):
 
 # input-slot -> weight-column maps of each packed layer (see mcn_pack_linear in include/mcn.h)
 def _ident(kin, tiles, offset=0):
+    """Slot -> feature map of a `kin`-wide activation held in `tiles` tiles of 16.  Full tiles are in natural
+    order; the ragged last tile is packed "q first" (feature j at slot 4(j%4) + j/4) so that its consumers need
+    only ceil(w/4) k-steps (include/mcn.h, mcn_pack_linear)."""
+    m = np.full(tiles * 16, -1, np.int32)
+    full = (kin // 16) * 16 if kin % 16 else kin
+    m[:full] = np.arange(full)
+    for j in range(kin - full):
+        m[full + 4 * (j % 4) + j // 4] = full + j
+    m[m >= 0] += offset
+    return m
+
+
+def _natural(kin, tiles, offset=0):
     m = np.full(tiles * 16, -1, np.int32)
     m[:kin] = np.arange(kin) + offset
     return m
@@ -59,10 +72,10 @@ def _ident(kin, tiles, offset=0):
 
 def _pack_plan():
     m3a = np.full(5 * 16, -1, np.int32)
-    m3a[:50] = 6 + np.arange(50)          # pooled features occupy tiles 0..3 -> mlp3.0 columns 6..55
-    m3a[64:70] = np.arange(6)             # self features occupy tile 4      -> mlp3.0 columns 0..5
+    m3a[:64] = _ident(50, 4, offset=6)    # pooled features occupy tiles 0..3 -> mlp3.0 columns 6..55
+    m3a[64:80] = _ident(6, 1)             # self features occupy tile 4      -> mlp3.0 columns 0..5
     #        name   state_dict key   kmap                KT  bias?
-    return [("m1a", "mlp1.0", _ident(13, 1), 1, True),
+    return [("m1a", "mlp1.0", _natural(13, 1), 1, True),
             ("m1b", "mlp1.2", _ident(150, 10), 10, True),
             ("m2a", "mlp2.0", _ident(100, 7), 7, True),
             ("m2b", "mlp2.2", _ident(100, 7), 7, True),
@@ -100,9 +113,11 @@ def pack_value_network(model, dev):
         NT = (nout + 15) // 16
         wf = np.zeros((NT, KT, 64, 4), np.float32)
         bf = np.zeros((NT, 64, 4), np.float32)
+        omap = _ident(nout, NT)             # outputs use the same ragged-tile packing their consumers assume
+        ip = C.POINTER(C.c_int32)
         rc = _hip.lib.mcn_pack_linear(W.ctypes.data_as(fp), b.ctypes.data_as(fp), nout, kin,
-                                          kmap.ctypes.data_as(C.POINTER(C.c_int32)), KT, wf.ctypes.data_as(fp),
-                                          bf.ctypes.data_as(fp) if with_bias else None)
+                                      kmap.ctypes.data_as(ip), KT, omap.ctypes.data_as(ip), NT,
+                                      wf.ctypes.data_as(fp), bf.ctypes.data_as(fp) if with_bias else None)
         _hip.check(rc, "mcn_pack_linear(%s)" % name)
         dw = torch.from_numpy(wf).to(dev)
         keep.append(dw)

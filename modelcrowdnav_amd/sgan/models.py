@@ -102,7 +102,7 @@ class TrajectoryGenerator(nn.Module):
             NT = (nout + 15) // 16
             wf, bf = np.zeros((NT, KT, 64, 4), np.float32), np.zeros((NT, 64, 4), np.float32)
             _hip.check(_hip.lib.mcn_pack_linear(W.ctypes.data_as(fp), b.ctypes.data_as(fp), nout, kin,
-                                                kmap.ctypes.data_as(C.POINTER(C.c_int32)), KT,
+                                                kmap.ctypes.data_as(C.POINTER(C.c_int32)), KT, None, NT,
                                                 wf.ctypes.data_as(fp), bf.ctypes.data_as(fp)), "mcn_pack_linear")
             for pre, arr in (("w_", wf), ("b_", bf)):
                 t = torch.from_numpy(arr).to(dev)

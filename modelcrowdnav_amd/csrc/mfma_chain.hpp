@@ -90,12 +90,15 @@ __device__ __forceinline__ void dense_acc(const f32x4 (&in)[KT], const f32x4 (&i
 // conflict-free ds_read_b128 (consecutive lanes, consecutive 16-B slots).  While chunk c is being
 // multiplied, the loads of chunk c+1 are already in flight (issued before the MFMAs, written to the other
 // buffer after them); one barrier per chunk.  Every thread of the workgroup must call this uniformly.
-constexpr int kStageThreads = 512;
-constexpr int kChunkTiles = 4;                                   // output tiles per staged chunk
-constexpr int kStageFloat4 = kChunkTiles * 10 * 64;              // largest chunk: 4 output tiles x KT = 10 input tiles
+constexpr int kStageThreads = 256;
+// output tiles per staged chunk: 4 for layers with <= 7 input tiles, 2 for the 10-tile ones, so that a chunk is
+// at most 28 KiB and two workgroups (2 x 2 buffers) fit the CU's 160 KiB of LDS
+__host__ __device__ constexpr int chunk_tiles(int KT) { return KT > 7 ? 2 : 4; }
+constexpr int kStageFloat4 = 28 * 64;                            // max over layers of chunk_tiles(KT) * KT * 64
+constexpr int kStageBias = 4 * 64;                               // bias fragments of the chunk's output tiles
 
 struct WeightStage {
-    float4 *buf;      // LDS, 2 * kStageFloat4 float4
+    float4 *buf;      // LDS, 2 * (kStageFloat4 + kStageBias) float4
     int tid;          // threadIdx.x, 0 .. kStageThreads-1
 };
 
@@ -106,32 +109,41 @@ __device__ __forceinline__ void dense_staged(const f32x4 (&in)[KT], const f32x4 
                                              const float4 *__restrict__ wf, const float4 *__restrict__ bf,
                                              const WeightStage &S, int lane)
 {
+    constexpr int kChunkTiles = chunk_tiles(KT);
     constexpr int CH = kChunkTiles * KT * 64;             // float4 per full chunk
+    static_assert(CH <= kStageFloat4, "chunk does not fit the LDS stage");
     constexpr int TOTAL = NT * KT * 64;
     constexpr int NCH = (NT + kChunkTiles - 1) / kChunkTiles;
     constexpr int PER = (CH + kStageThreads - 1) / kStageThreads;
-    float4 pre[PER];
-    auto gload = [&](int c) {
+    constexpr int BCH = kChunkTiles * 64;                 // bias float4 per chunk
+    // LDS-DMA staging: the stage image is lane-linear (thread i's float4 lands at float4 slot i), which is
+    // exactly what global_load_lds writes (wave-uniform LDS base + lane * 16 B), so the weights go L2 -> LDS
+    // without passing through (and pinning) VGPRs.  Biases ride along in a small tail region so that no ordinary
+    // global load sits between a DMA and the barrier that retires it.
+    const int wave_base = S.tid & ~63;
+    auto stage = [&](int c, int b) {
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int i = S.tid + k * kStageThreads;
-            pre[k] = (i < CH && c * CH + i < TOTAL) ? wf[c * CH + i] : make_float4(0, 0, 0, 0);
+            if (i < CH && c * CH + i < TOTAL)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(wf + c * CH + i),
+                    (__attribute__((address_space(3))) void *)(S.buf + b * (kStageFloat4 + kStageBias) + k * kStageThreads + wave_base),
+                    16, 0, 0);
         }
+        if (!HAS_INIT && S.tid < BCH && c * BCH + S.tid < NT * 64)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(bf + c * BCH + S.tid),
+                (__attribute__((address_space(3))) void *)(S.buf + b * (kStageFloat4 + kStageBias) + kStageFloat4 + wave_base),
+                16, 0, 0);
     };
-    auto lstore = [&](int b) {
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int i = S.tid + k * kStageThreads;
-            if (i < CH) S.buf[b * kStageFloat4 + i] = pre[k];
-        }
-    };
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    stage(0, 0);
+    __syncthreads();                                      // drains vmcnt (the DMA) and orders it before the reads
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        if (c + 1 < NCH) gload(c + 1);
-        const float4 *wc = S.buf + (c & 1) * kStageFloat4;
+        if (c + 1 < NCH) stage(c + 1, (c + 1) & 1);
+        const float4 *wc = S.buf + (c & 1) * (kStageFloat4 + kStageBias);
+        const float4 *bc = wc + kStageFloat4;
 #pragma unroll
         for (int h2 = 0; h2 < kChunkTiles; h2 += 2) {
             const int n = kChunkTiles * c + h2;
@@ -143,8 +155,8 @@ __device__ __forceinline__ void dense_staged(const f32x4 (&in)[KT], const f32x4 
                     a0 = init[n];
                     if (two) a1 = init[n + 1];
                 } else {
-                    { const float4 b = bf[n * 64 + lane]; a0 = (f32x4){b.x, b.y, b.z, b.w}; }
-                    if (two) { const float4 b = bf[(n + 1) * 64 + lane]; a1 = (f32x4){b.x, b.y, b.z, b.w}; }
+                    { const float4 b = bc[h2 * 64 + lane]; a0 = (f32x4){b.x, b.y, b.z, b.w}; }
+                    if (two) { const float4 b = bc[(h2 + 1) * 64 + lane]; a1 = (f32x4){b.x, b.y, b.z, b.w}; }
                 }
 #pragma unroll
                 for (int t = 0; t < KT; ++t) {
@@ -175,7 +187,6 @@ __device__ __forceinline__ void dense_staged(const f32x4 (&in)[KT], const f32x4 
                 if (two) out[n + 1] = a1;
             }
         }
-        if (c + 1 < NCH) lstore((c + 1) & 1);
         __syncthreads();
     }
 }

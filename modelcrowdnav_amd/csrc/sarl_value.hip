@@ -76,7 +76,7 @@ constexpr int kSarlWaves = kStageThreads / 64;     // 8 wavefronts share one LDS
 
 __global__ __launch_bounds__(kSarlWaves * 64, 2) void sarl_value_kernel(const SarlParams p)
 {
-    __shared__ float4 s_stage[2 * kStageFloat4];
+    __shared__ float4 s_stage[2 * (kStageFloat4 + kStageBias)];
     const WeightStage S{s_stage, (int)threadIdx.x};
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;

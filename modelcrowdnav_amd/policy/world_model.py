@@ -153,3 +153,85 @@ def generator_from_arrays(arrays, prefix, device=None):
     gen = TrajectoryGenerator(pooling_type=pooling, device=device)
     gen.load_state_dict(sd)
     return gen
+
+
+# ---------------------------------------------------------------------------------------------
+# Learned one-step world models other than SGAN (reference: world_model.py:17-106).  These are the next tier
+# (SURVEY.md 8f, f3): kept as torch modules with the reference's parameter names so their checkpoints load and
+# ModelCrowdSim can call them (`sim_world(Tensor[B,4N]) -> Tensor[B,2N]`, model_crowd_sim.py:404-407); they run
+# through torch's ROCm GEMMs, not through hand-written kernels.
+def init_weight(m):
+    if type(m) == nn.Linear:
+        nn.init.xavier_uniform_(m.weight)
+
+
+class MlpWorld(nn.Module):
+    """world_model.py:22-51: 4N -> 128 -> 64 -> 12 -> 2N with dropout and a final tanh."""
+
+    def __init__(self, num_human, drop_rate=0.5, multihuman=True):
+        super().__init__()
+        if not multihuman:
+            num_human = 1
+        self.mlp = nn.Sequential(nn.Linear(num_human * 4, 128), nn.ReLU(True), nn.Dropout(drop_rate),
+                                 nn.Linear(128, 64), nn.ReLU(True), nn.Dropout(drop_rate),
+                                 nn.Linear(64, 12), nn.ReLU(True), nn.Linear(12, num_human * 2), nn.Tanh())
+        self.mse = 0
+        self.device = None
+
+    def forward(self, x):
+        return self.mlp(x)
+
+    def noise_pre(self, x):
+        import math
+        x = self.forward(x)
+        return x + (torch.randn(x.shape) * math.sqrt(self.mse)).to(self.device)
+
+
+class AttentionWorld(nn.Module):
+    """world_model.py:54-106: SARL-style attention over humans, 2 outputs per human (no final tanh)."""
+
+    def __init__(self, input_dim=4, with_global_state=True):
+        super().__init__()
+        from .cadrl import mlp
+        self.input_dim = input_dim
+        self.with_global_state = with_global_state
+        self.global_state_dim = 100
+        self.mlp1 = mlp(input_dim, [150, 100], last_relu=True)
+        self.mlp2 = mlp(100, [100, 50])
+        self.attention = mlp(200 if with_global_state else 100, [100, 100, 1])
+        self.mlp3_input_dim = 50 + input_dim
+        self.mlp3 = mlp(self.mlp3_input_dim, [150, 100, 100, 2])
+        self.attention_weights = None
+        self.output_func = nn.Tanh()
+
+    def forward(self, in_state):
+        state = in_state.view(in_state.shape[0], -1, self.input_dim)
+        B, N, _ = state.shape
+        h = self.mlp1(state.reshape(B * N, -1))
+        feat = self.mlp2(h)
+        if self.with_global_state:
+            g = h.view(B, N, -1).mean(1, keepdim=True).expand(B, N, self.global_state_dim)
+            att_in = torch.cat([h, g.reshape(B * N, -1)], dim=1)
+        else:
+            att_in = h
+        scores = self.attention(att_in).view(B, N)
+        e = torch.exp(scores) * (scores != 0).float()
+        w = (e / e.sum(dim=1, keepdim=True)).unsqueeze(2)
+        self.attention_weights = w[0, :, 0].data.cpu().numpy()
+        pooled = (w * feat.view(B, N, -1)).sum(dim=1, keepdim=True).expand(B, N, feat.shape[1])
+        joint = torch.cat([state, pooled], dim=2)
+        return self.mlp3(joint.reshape(B * N, self.mlp3_input_dim)).view(B, -1)
+
+
+class VecTorchWorld(object):
+    """Adapter: a [B,4N] -> [B,2N] module (MlpWorld / AttentionWorld) as a VecModelCrowdSim `sim_world`."""
+
+    def __init__(self, module, env):
+        self.module, self.env = module, env
+
+    def __call__(self, hpos, noise=None):
+        env = self.env
+        x = torch.cat([env.hpos, env.hvel], dim=2).reshape(env.num_envs, -1).float()
+        with torch.no_grad():
+            v = self.module(x)
+        return v.view(env.num_envs, -1, 2).double().contiguous()

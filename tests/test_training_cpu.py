@@ -109,3 +109,19 @@ def test_data_parallel_trainer_world2(tmp_path):
     tr.optimize_epoch(2)
     for k, v in model.state_dict().items():
         assert torch.allclose(v, w0[k], rtol=0, atol=2e-6), k
+
+
+def test_world_model_modules_match_reference_parameter_names():
+    """MlpWorld / AttentionWorld keep the reference's state_dict keys (world_model.py:22-106) and shapes."""
+    from modelcrowdnav_amd.policy.world_model import MlpWorld, AttentionWorld
+    m = MlpWorld(5)
+    assert list(m.state_dict().keys()) == ["mlp.0.weight", "mlp.0.bias", "mlp.3.weight", "mlp.3.bias",
+                                           "mlp.6.weight", "mlp.6.bias", "mlp.8.weight", "mlp.8.bias"]
+    m.eval()
+    assert m(torch.zeros(3, 20)).shape == (3, 10)
+    a = AttentionWorld()
+    keys = list(a.state_dict().keys())
+    assert keys[0] == "mlp1.0.weight" and "attention.4.bias" in keys and "mlp3.6.weight" in keys
+    assert a.state_dict()["mlp3.0.weight"].shape == (150, 54) and a.state_dict()["mlp3.6.weight"].shape == (2, 100)
+    out = a(torch.randn(4, 20))
+    assert out.shape == (4, 10) and a.attention_weights.shape == (5,)

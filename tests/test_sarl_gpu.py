@@ -110,3 +110,27 @@ def test_rewards_are_float64_exact():
     _, _, values = pol.predict_batch(env, want_values=True)
     ref = cport.lookahead_reward(st, pol._action_table, 0.25)
     assert np.array_equal(values.cpu().numpy(), ref)
+
+
+def test_unicycle_lookahead_matches_oracle():
+    """(v, r) action table, heading-dependent propagate and the theta feature (cadrl.py:97-99,118-124,236-237)."""
+    import torch
+    rng = np.random.RandomState(21)
+    E, N = 24, 5
+    pol = _policy(seed=5)
+    pol.kinematics = "unicycle"
+    pol.action_space = None
+    env = H.make_vec_env(E, N, kinematics="unicycle")
+    st = H.random_state(rng, E, N)
+    st.rtheta[:] = rng.uniform(-3, 3, E)
+    H.upload(env, st)
+    actions, best, values = pol.predict_batch(env, want_values=True)
+    values = values.cpu().numpy()
+    table = pol._action_table
+    assert table.shape == (81, 2) and table[1, 1] == -np.pi / 4          # (speed, rotation) rows
+    w = {k: v.detach().cpu() for k, v in pol.model.state_dict().items()}
+    for e in range(0, E, 4):
+        row = [st.rpx[e], st.rpy[e], st.rvx[e], st.rvy[e], st.rr[e], st.rgx[e], st.rgy[e], 1.0, st.rtheta[e]]
+        hum = np.stack([st.hpx[e], st.hpy[e], st.hvx[e], st.hvy[e], st.hr[e]], 1)
+        ref, idx = pyref.sarl_predict(w, row, hum, table, kinematics="unicycle")
+        np.testing.assert_allclose(values[e], ref, rtol=0, atol=TOL)

@@ -166,7 +166,7 @@ struct Lp3Step {
     }
 };
 
-constexpr int kLp3StaticMax = 5;      // above this the unrolled code grows as NL^3: use the generic solver
+constexpr int kLp3StaticMax = 10;     // above this the unrolled code grows as NL^3: use the generic solver
 
 // NC candidates in insertion order -> new velocity.  cpv[c] = (px,py,vx,vy), crad[c] = radius.
 template <int NC>

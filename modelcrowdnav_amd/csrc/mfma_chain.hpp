@@ -92,9 +92,9 @@ __device__ __forceinline__ void dense_acc(const f32x4 (&in)[KT], const f32x4 (&i
 // buffer after them); one barrier per chunk.  Every thread of the workgroup must call this uniformly.
 constexpr int kStageThreads = 256;
 // output tiles per staged chunk: 4 for layers with <= 7 input tiles, 2 for the 10-tile ones, so that a chunk is
-// at most 28 KiB and two workgroups (2 x 2 buffers) fit the CU's 160 KiB of LDS
-__host__ __device__ constexpr int chunk_tiles(int KT) { return KT > 7 ? 2 : 4; }
-constexpr int kStageFloat4 = 28 * 64;                            // max over layers of chunk_tiles(KT) * KT * 64
+// at most 32 KiB and two workgroups (2 x 2 buffers + bias tails = 2 x 72 KiB) fit the CU's 160 KiB of LDS
+__host__ __device__ constexpr int chunk_tiles(int KT) { return KT > 16 ? 1 : (KT > 7 ? 2 : 4); }
+constexpr int kStageFloat4 = 32 * 64;                            // max over layers of chunk_tiles(KT) * KT * 64 (32 KiB)
 constexpr int kStageBias = 4 * 64;                               // bias fragments of the chunk's output tiles
 
 struct WeightStage {

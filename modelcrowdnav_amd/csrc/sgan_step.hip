@@ -75,7 +75,7 @@ __device__ __forceinline__ f32x4 tile_xy(float x, float y, int q)
     return v;
 }
 
-constexpr int kSganWaves = 4;
+constexpr int kSganWaves = kStageThreads / 64;      // the decode kernel shares one LDS weight stage per workgroup
 
 __global__ __launch_bounds__(kSganWaves * 64) void sgan_encode_kernel(const SganParams p)
 {
@@ -133,13 +133,15 @@ __global__ __launch_bounds__(kSganWaves * 64) void sgan_encode_kernel(const Sgan
     }
 }
 
-__global__ __launch_bounds__(kSganWaves * 64) void sgan_decode_kernel(const SganParams p)
+__global__ __launch_bounds__(kSganWaves * 64, 2) void sgan_decode_kernel(const SganParams p)
 {
+    __shared__ float4 s_stage[2 * (kStageFloat4 + kStageBias)];
+    const WeightStage S{s_stage, (int)threadIdx.x};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, q = lane >> 4;
     const long nped = (long)p.E * p.N;
     const long ped0 = ((long)blockIdx.x * kSganWaves + wave) * 16;
-    if (ped0 >= nped) return;
+    // no early exit: every wavefront of the workgroup takes part in the weight-staging barriers
     long ped = ped0 + j;
     const bool valid = ped < nped;
     if (!valid) ped = nped - 1;
@@ -163,12 +165,12 @@ __global__ __launch_bounds__(kSganWaves * 64) void sgan_decode_kernel(const Sgan
             const float4 a = src[q], b = src[4 + q];
             f32x4 xin[1] = {tile_xy(theirs.x - mine.x, theirs.y - mine.y, q)};       // P_k - P_i (models.py:221)
             f32x4 emb[1];
-            dense<1, 1, false>(xin, emb, p.f.w_pemb, p.f.b_pemb, lane);
+            dense_staged<1, 1, false, false>(xin, nullptr, emb, p.f.w_pemb, p.f.b_pemb, S, lane);
             f32x4 cat[3] = {emb[0], (f32x4){a.x, a.y, a.z, a.w}, (f32x4){b.x, b.y, b.z, b.w}};
             f32x4 hid[32];
-            dense<3, 32, true>(cat, hid, p.f.w_p1, p.f.b_p1, lane);
+            dense_staged<3, 32, true, false>(cat, nullptr, hid, p.f.w_p1, p.f.b_p1, S, lane);
             f32x4 o[1];
-            dense<32, 1, true>(hid, o, p.f.w_p2, p.f.b_p2, lane);
+            dense_staged<32, 1, true, false>(hid, nullptr, o, p.f.w_p2, p.f.b_p2, S, lane);
 #pragma unroll
             for (int r = 0; r < 4; ++r) pool[r] = fmaxf(pool[r], o[0][r]);
         }

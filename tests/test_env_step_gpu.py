@@ -270,3 +270,40 @@ def test_single_env_and_tiny_batches():
             for key in ref:
                 assert np.array_equal(got[key], ref[key]), (E, N, key)
             H.assert_state_equal(H.download(env), ref_st)
+
+
+def test_config5_shape_32768x10_exact_and_shard_invariant():
+    """BASELINE configs[4] shape on one GPU: 32768 envs x 10 humans (ORCA, 9 neighbours each).
+    (a) 6 steps bit-exact against the C oracle for the whole batch; (b) stepping the batch as 8 shards of 4096
+    (what 8 ranks do) gives bit-identical state to stepping it whole -- no cross-env coupling anywhere."""
+    torch = _torch()
+    from modelcrowdnav_amd.envs import scenarios as S
+    E, N, T = 32768, 10, 6
+    env = H.make_vec_env(E, N)
+    env.track_human_times = False; env.export_human_actions = False
+    pool = S.scenario_pool(env.spec(), "test", range(64), N, "circle_crossing")
+    scen = pool[np.arange(E) % 64]
+    rng = np.random.RandomState(5)
+    scen[:, :, [S.VX, S.VY]] = rng.uniform(-0.5, 0.5, (E, N, 2))          # decorrelate the 512 copies of a case
+    env.load_scenarios(scen)
+    st = H.download(env)
+    cfg = H.oracle_cfg_for(env)
+    acts = rng.uniform(-0.7, 0.7, (T, E, 2))
+    shards = []
+    for r in range(8):
+        sub = H.make_vec_env(4096, N)
+        sub.track_human_times = False; sub.export_human_actions = False
+        sub.load_scenarios(scen[r * 4096:(r + 1) * 4096])
+        shards.append(sub)
+    for t in range(T):
+        ob, reward, done, info = env.step(torch.from_numpy(acts[t]).to(env.device))
+        ref = cport.env_step(cfg, st, acts[t, :, 0].copy(), acts[t, :, 1].copy(), update=True)
+        assert np.array_equal(done.cpu().numpy(), ref["done"]) and np.array_equal(info.cpu().numpy(), ref["info"]), t
+        assert np.array_equal(reward.cpu().numpy(), ref["reward"]), t
+        for r, sub in enumerate(shards):
+            sub.step(torch.from_numpy(acts[t, r * 4096:(r + 1) * 4096]).to(sub.device))
+    H.assert_state_equal(H.download(env), st, fields=[f for f in H.STATE_FIELDS if f != "human_times"])
+    whole = env.hpos.cpu().numpy()
+    parts = np.concatenate([s_.hpos.cpu().numpy() for s_ in shards], 0)
+    assert np.array_equal(whole, parts)
+    assert np.array_equal(env.rpos.cpu().numpy(), np.concatenate([s_.rpos.cpu().numpy() for s_ in shards], 0))

@@ -9,9 +9,14 @@ __device__ __forceinline__ double norm2(double x0, double x1) { return sqrt(fma(
 // crowd_sim/envs/utils/utils.py:4-26 with (x3, y3) = (0, 0), the env's only call shape
 __device__ __forceinline__ double p2s_origin(double x1, double y1, double x2, double y2)
 {
+    // Branch-free form with identical results: for a degenerate segment (px == py == 0) the reference returns
+    // norm((0 - x1, 0 - y1)); with u forced to 0 the general formula gives norm((x1 + 0*0, y1 + 0*0)) -- the same
+    // two squares under one fma and one sqrt.  Keeping one straight-line block lets the scheduler interleave this
+    // long float64 dependency chain with the other independent ones around it.
     const double px = x2 - x1, py = y2 - y1;
-    if (px == 0 && py == 0) return norm2(0.0 - x1, 0.0 - y1);
+    const bool degenerate = (px == 0) & (py == 0);
     double u = ((0.0 - x1) * px + (0.0 - y1) * py) / (px * px + py * py);
+    u = degenerate ? 0.0 : u;
     if (u > 1) u = 1; else if (u < 0) u = 0;
     const double x = x1 + u * px, y = y1 + u * py;
     return norm2(x - 0.0, y - 0.0);

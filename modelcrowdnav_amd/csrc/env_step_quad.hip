@@ -130,6 +130,7 @@ template <int NT, int VIS, bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? 128 : 64) void env_step_quad_kernel(const StepParams p)
 {
     __shared__ int s_dn[16], s_case[16];
+    if (p.debug_noop) return;
     const int role = SPLIT ? (int)(threadIdx.x >> 6) : -1;      // 0: ORCA, 1: pairwise + ladder, -1: both
     const bool do_orca = role != 1, do_pair = role != 0;
     constexpr int NC = NT - 1 + VIS;          // candidates per human, <= 4
@@ -272,18 +273,20 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void env_step_quad_kernel(const S
         eff.x = act.x * cos(act.y + rtheta);
         eff.y = act.x * sin(act.y + rtheta);
     }
-    double cd = INFINITY;
-    if (k == 0) {
+    // every lane of the quad evaluates the (same) swept distance: no branch, so this float64 chain interleaves
+    // with the overlap test and the goal test below instead of serialising behind a divergent region
+    double cd;
+    {
         const double px = pos.x - rpos.x, py = pos.y - rpos.y;
         const double vx = vel.x - eff.x, vy = vel.y - eff.y;
         cd = p2s_origin(px, py, px + vx * dt, py + vy * dt) - rad - rrad;
     }
-    int hh = 0;
-    if (c.count_hh && cand_h && j > h) {        // each unordered pair exactly once (crowd_sim.py:369-374)
+    int hh;
+    {                                           // each unordered pair exactly once (crowd_sim.py:369-374)
         const double dx = pos.x - cpos.x, dy = pos.y - cpos.y;
-        hh = (sqrt(dx * dx + dy * dy) - rad - crd) < 0 ? 1 : 0;
+        const bool counted = c.count_hh && cand_h && j > h;
+        hh = (counted && (sqrt(dx * dx + dy * dy) - rad - crd) < 0) ? 1 : 0;
     }
-    cd = qbd<0>(cd);                                                    // the quad's swept distance
     hh += __builtin_amdgcn_update_dpp(0, hh, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
     hh += __builtin_amdgcn_update_dpp(0, hh, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
     int hh_sum = 0;

@@ -362,7 +362,7 @@ static void dispatch(const StepParams &p, int blocks, hipStream_t stream)
         // (human_num 5 / 10 in the configs, 5,7,9 in test_mul_env.py:31-33, 1..5 in the 'mixed' rule)
 #define MCN_CASE(NT_) case NT_: if (vis) launch_one<BLOCK, NT_, 1, MCN_HUMANS_ORCA, 2>(p, blocks, stream); \
                                else     launch_one<BLOCK, NT_, 0, MCN_HUMANS_ORCA, 2>(p, blocks, stream); return;
-        switch (p.N) {
+        switch (p.force_generic ? 0 : p.N) {
             MCN_CASE(1) MCN_CASE(2) MCN_CASE(3) MCN_CASE(4) MCN_CASE(5) MCN_CASE(6) MCN_CASE(7) MCN_CASE(8) MCN_CASE(9) MCN_CASE(10)
             default: break;
         }

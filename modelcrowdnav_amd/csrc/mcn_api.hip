@@ -63,6 +63,8 @@ int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *
         // E <= 8192 at 5 humans); above that the lane-per-human kernel wins on throughput.  Inside the quad
         // kernel, ORCA and the float64 pairwise work go to two cooperating wavefronts only while BOTH still get a
         // SIMD of their own (grid <= 512 workgroups).  MCN_QUAD_MAX_ENVS / MCN_QUAD_SPLIT override (tests, tuning).
+        const char *env_gen = getenv("MCN_FORCE_GENERIC");
+        p.force_generic = env_gen ? atoi(env_gen) : 0;
         const char *env_noop = getenv("MCN_DEBUG_NOOP");
         p.debug_noop = env_noop ? atoi(env_noop) : 0;
         const char *env_max = getenv("MCN_QUAD_MAX_ENVS");

@@ -46,12 +46,15 @@ def _step_both(env, st, ax, ay, update, policy=cport.HUMANS_ORCA, given=None):
                                                  (7, False, True), (9, True, False), (13, False, True),
                                                  (32, False, False)])
 @pytest.mark.parametrize("update", [True, False])
-@pytest.mark.parametrize("kernel", ["auto", "lane-per-human", "quad", "quad-split"])
+@pytest.mark.parametrize("kernel", ["auto", "lane-per-human", "run-time-N", "quad", "quad-split"])
 def test_step_matches_oracle_bitexact(N, visible, randomize, update, kernel, monkeypatch):
-    # the same arithmetic exists in three decompositions (env_step.hip, env_step_quad.hip +- wavefront split);
-    # MCN_QUAD_* pin which one the dispatcher picks
+    # the same arithmetic exists in several decompositions (env_step.hip with compile-time or run-time N,
+    # env_step_quad.hip +- wavefront split); MCN_QUAD_* / MCN_FORCE_GENERIC pin which one the dispatcher picks
     if kernel == "lane-per-human":
         monkeypatch.setenv("MCN_QUAD_MAX_ENVS", "0")
+    elif kernel == "run-time-N":
+        monkeypatch.setenv("MCN_QUAD_MAX_ENVS", "0")
+        monkeypatch.setenv("MCN_FORCE_GENERIC", "1")
     elif kernel.startswith("quad"):
         if N - 1 + int(visible) > 4:
             pytest.skip("quad kernel handles at most 4 neighbours")

@@ -49,40 +49,6 @@ __device__ __forceinline__ void dense(const f32x4 (&in)[KT], f32x4 (&out)[NT], c
     }
 }
 
-// same, but accumulates onto out[] (used to fold the global-state half of attention layer 0)
-template <int KT, int NT, bool RELU>
-__device__ __forceinline__ void dense_acc(const f32x4 (&in)[KT], const f32x4 (&init)[NT], f32x4 (&out)[NT],
-                                          const float4 *__restrict__ wf, int lane)
-{
-#pragma unroll
-    for (int n = 0; n < NT; n += 2) {
-        const bool two = (n + 1 < NT);
-        f32x4 a0 = init[n], a1 = {0, 0, 0, 0};
-        if (two) a1 = init[n + 1];
-#pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            const float4 w0 = wf[(n * KT + t) * 64 + lane];
-            float4 w1 = make_float4(0, 0, 0, 0);
-            if (two) w1 = wf[((n + 1) * KT + t) * 64 + lane];
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, in[t][0], a0, 0, 0, 0);
-            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, in[t][0], a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, in[t][1], a0, 0, 0, 0);
-            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, in[t][1], a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, in[t][2], a0, 0, 0, 0);
-            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, in[t][2], a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, in[t][3], a0, 0, 0, 0);
-            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, in[t][3], a1, 0, 0, 0);
-        }
-        if (RELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { a0[r] = fmaxf(a0[r], 0.0f); a1[r] = fmaxf(a1[r], 0.0f); }
-        }
-        out[n] = a0;
-        if (two) out[n + 1] = a1;
-    }
-}
-
-
 // ------------------------------------------------------------------------------------------------
 // LDS-staged variant: the workgroup's waves all run the same layer on different batch tiles, so the
 // weight fragments are fetched from L2 ONCE per workgroup into a double-buffered LDS stage (one chunk =

@@ -235,8 +235,24 @@ class VecCrowdSim(object):
         return ob, self.reward, self.done, self.info
 
     def onestep_lookahead(self, actions):
-        """crowd_sim.py:325-329 (look_ahead_in_sim=False path)."""
+        """crowd_sim.py:325-329: a non-mutating step; with look_ahead_in_sim the humans' next states come from the
+        learned world model instead of ORCA (step_in_sim, crowd_sim.py:633-696)."""
+        if self.look_ahead_in_sim:
+            return self.step_in_sim(actions)
         return self.step(actions, update=False)
+
+    def step_in_sim(self, actions):
+        """crowd_sim.py:633-696: same collision / reward ladder (no human-human check), next human states =
+        position + sim_world velocity * dt.  `sim_world` is a VecSGANWorld / VecTorchWorld style callable."""
+        if self.sim_world is None:
+            raise AttributeError("sim_world has to be set for look_ahead_in_sim")
+        new_v = self.sim_world(self.hpos)
+        keep = self.count_hh
+        self.count_hh = False
+        try:
+            return self.step(actions, update=False, given_v=new_v)
+        finally:
+            self.count_hh = keep
 
     # ---------------------------------------------------------------- fused rollout bookkeeping
     def attach_rollout(self, gamma, pool=None, case_stride=1, first_cases=None, fin_slots=1):

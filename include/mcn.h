@@ -75,13 +75,20 @@ typedef struct mcn_env_state {
     double *human_times;                       /* [E*N] or NULL */
 } mcn_env_state;
 
+/* What one env reports per step, as ONE 24-byte record: the kernel issues one store per env instead of five
+ * scattered 1..8-byte ones (at a million envs the narrow per-env streams, not the bytes, limit the kernel). */
+typedef struct mcn_step_rec {
+    double  reward;
+    double  dmin;         /* min boundary distance robot-human over the step */
+    uint8_t done;
+    uint8_t info;         /* MCN_INFO_* */
+    uint16_t reserved;
+    int32_t hh_count;     /* human-human overlaps (the reference only logs them) */
+} mcn_step_rec;
+
 /* Per-step outputs (device pointers). */
 typedef struct mcn_env_out {
-    double  *reward;      /* [E] */
-    double  *dmin;        /* [E] min boundary distance robot-human over the step (inf if N==0) */
-    uint8_t *done;        /* [E] */
-    uint8_t *info;        /* [E] MCN_INFO_* */
-    int32_t *hh_count;    /* [E] human-human overlaps (reference only logs them) */
+    mcn_step_rec *rec;    /* [E] */
     double  *human_act;   /* [E*N][2] velocity each human chose, or NULL */
     double  *nobs_pos;    /* [E*N][2] next observable positions  (update == 0 only) */
     double  *nobs_vel;    /* [E*N][2] next observable velocities (update == 0 only) */
@@ -91,28 +98,32 @@ typedef struct mcn_env_out {
  * Optional fused bookkeeping of Explorer.run_k_episodes (crowd_nav/utils/explorer.py:54-125)
  * and vector-env style auto-reset.  Any pointer may be NULL to disable that part.
  */
+/* Rollout state of one env, ONE 32-byte record (one load + one store per step). */
+typedef struct mcn_roll_rec {
+    double  ep_return;         /* running discounted sum */
+    int32_t ep_steps;          /* steps taken in the running episode */
+    int32_t fin_count;         /* episodes finished so far */
+    int32_t next_case;         /* pool index used at the next reset; advanced by case_stride mod pool_size */
+    int32_t danger_count;      /* steps whose info was Danger ("too close", explorer.py:88-90) */
+    double  danger_dist_sum;   /* sum of their min_dist */
+} mcn_roll_rec;
+
 typedef struct mcn_rollout {
     /* discounted return: sum_t disc_table[t] * r_t, disc_table[t] = pow(gamma, t*dt*v_pref) (explorer.py:124) */
     const double *disc_table;  int32_t disc_len;
-    double  *ep_return;        /* [E] running sum       */
-    int32_t *ep_steps;         /* [E] steps taken in the running episode */
+    mcn_roll_rec *state;       /* [E], or NULL: no return accounting */
     /* records of finished episodes: with fin_slots == 1 slot 0 holds the latest episode of env e; with
      * fin_slots > 1 episode number k < fin_slots of env e lands in slot k and later ones are not recorded */
     double  *fin_return;       /* [fin_slots][E] */
     double  *fin_time;         /* [fin_slots][E] env.global_time at the end (explorer.py:95,99) */
     uint8_t *fin_info;         /* [fin_slots][E] */
-    int32_t *fin_count;        /* [E] episodes finished so far */
     int32_t  fin_slots;        /* >= 1 */
-    /* "too close" statistics (explorer.py:88-90,137-140) */
-    int32_t *danger_count;     /* [E] steps whose info was Danger, or NULL */
-    double  *danger_dist_sum;  /* [E] sum of their min_dist, or NULL */
     /* auto-reset from a pool of host-generated scenarios (bit-exact CrowdSim.reset output) */
     const double *pool_hpos, *pool_hgoal;                /* [P*N][2] */
     const double *pool_hrad, *pool_hvpref;               /* [P*N]    */
     const double *pool_hvel;                             /* [P*N][2] or NULL (zeros) */
     int32_t pool_size;
-    int32_t *next_case;        /* [E] index into the pool used at the next reset; advanced by case_stride mod pool_size */
-    int32_t case_stride;
+    int32_t case_stride;       /* pool resets need `state` (its next_case field) */
     double  robot_start[2], robot_goal[2], robot_theta0;  /* crowd_sim.py:284 */
 } mcn_rollout;
 

@@ -37,17 +37,43 @@ class EnvState(C.Structure):
 
 
 class EnvOut(C.Structure):
-    _fields_ = [(k, _vp) for k in ("reward", "dmin", "done", "info", "hh_count", "human_act", "nobs_pos", "nobs_vel")]
+    _fields_ = [(k, _vp) for k in ("rec", "human_act", "nobs_pos", "nobs_vel")]
+
+
+class StepRec(C.Structure):
+    """mcn_step_rec: what one env reports per step (24 bytes)."""
+    _fields_ = [("reward", _d), ("dmin", _d), ("done", C.c_uint8), ("info", C.c_uint8), ("reserved", C.c_uint16),
+                ("hh_count", _i)]
+
+
+class RollRec(C.Structure):
+    """mcn_roll_rec: rollout state of one env (32 bytes)."""
+    _fields_ = [("ep_return", _d), ("ep_steps", _i), ("fin_count", _i), ("next_case", _i), ("danger_count", _i),
+                ("danger_dist_sum", _d)]
+
+
+def step_rec_views(rec):
+    """Typed strided views of a [E,3] float64 tensor laid out as mcn_step_rec[E]."""
+    import torch
+    b, w = rec.view(torch.uint8), rec.view(torch.int32)
+    return dict(reward=rec[:, 0], dmin=rec[:, 1], done=b[:, 16], info=b[:, 17], hh_count=w[:, 5])
+
+
+def roll_rec_views(state):
+    """Typed strided views of a [E,4] float64 tensor laid out as mcn_roll_rec[E]."""
+    import torch
+    w = state.view(torch.int32)
+    return dict(ep_return=state[:, 0], ep_steps=w[:, 2], fin_count=w[:, 3], next_case=w[:, 4],
+                danger_count=w[:, 5], danger_dist_sum=state[:, 3])
 
 
 class Rollout(C.Structure):
     _fields_ = [
         ("disc_table", _vp), ("disc_len", _i),
-        ("ep_return", _vp), ("ep_steps", _vp),
-        ("fin_return", _vp), ("fin_time", _vp), ("fin_info", _vp), ("fin_count", _vp), ("fin_slots", _i),
-        ("danger_count", _vp), ("danger_dist_sum", _vp),
+        ("state", _vp),
+        ("fin_return", _vp), ("fin_time", _vp), ("fin_info", _vp), ("fin_slots", _i),
         ("pool_hpos", _vp), ("pool_hgoal", _vp), ("pool_hrad", _vp), ("pool_hvpref", _vp), ("pool_hvel", _vp),
-        ("pool_size", _i), ("next_case", _vp), ("case_stride", _i),
+        ("pool_size", _i), ("case_stride", _i),
         ("robot_start", _d * 2), ("robot_goal", _d * 2), ("robot_theta0", _d),
     ]
 

@@ -97,8 +97,9 @@ void env_step_kernel(const StepParams p)
     }
     double2 rpos = make_double2(0, 0), rvel = rpos, rgoal = rpos, rattr = rpos, act = rpos;
     double rtheta = 0, gtime = 0;
-    int next_case = 0, ep_t = 0, ep_k = 0;
-    double ep_ret = 0, ep_disc = 0;
+    int next_case = 0;
+    double ep_disc = 0;
+    mcn_roll_rec rs = {0, 0, 0, 0, 0, 0};
     if (leader) {
         rpos  = reinterpret_cast<const double2 *>(p.st.rpos)[e];
         rvel  = reinterpret_cast<const double2 *>(p.st.rvel)[e];
@@ -107,14 +108,12 @@ void env_step_kernel(const StepParams p)
         act   = reinterpret_cast<const double2 *>(p.actions)[e];
         gtime = p.st.gtime[e];
         if (c.robot_kinematics == MCN_KIN_UNICYCLE) rtheta = p.st.rtheta[e];
-        if (p.has_roll && p.roll.next_case) next_case = p.roll.next_case[e];
-        // rollout bookkeeping operands are fetched now, so their latency hides under the ORCA solve instead of
-        // forming a dependent load chain (steps -> discount) at the very end of the kernel
-        if (p.has_roll && p.roll.ep_return) {
-            ep_t = p.roll.ep_steps[e];
-            ep_ret = p.roll.ep_return[e];
-            ep_disc = p.roll.disc_table[ep_t < p.roll.disc_len ? ep_t : p.roll.disc_len - 1];
-            ep_k = p.roll.fin_count ? p.roll.fin_count[e] : 0;
+        // the rollout record is fetched now, so its latency hides under the ORCA solve instead of forming a
+        // dependent load chain (steps -> discount) at the very end of the kernel
+        if (p.has_roll && p.roll.state) {
+            rs = p.roll.state[e];                       // one 32-byte record
+            next_case = rs.next_case;
+            ep_disc = p.roll.disc_table[rs.ep_steps < p.roll.disc_len ? rs.ep_steps : p.roll.disc_len - 1];
         }
     }
     // effective robot velocity for the swept test (crowd_sim.py:350-355)
@@ -255,11 +254,9 @@ void env_step_kernel(const StepParams p)
         else if (reaching)                  { rew = c.success_reward; dn = 1; inf = MCN_INFO_REACHGOAL; }
         else if (dmin < c.discomfort_dist)  { rew = (dmin - c.discomfort_dist) * c.discomfort_penalty_factor * dt; dn = 0; inf = MCN_INFO_DANGER; }
         else                                { rew = 0; dn = 0; inf = MCN_INFO_NOTHING; }
-        p.out.reward[e] = rew;
-        p.out.dmin[e] = dmin;
-        p.out.done[e] = (uint8_t)dn;
-        p.out.info[e] = (uint8_t)inf;
-        p.out.hh_count[e] = hh_sum;
+        mcn_step_rec o;
+        o.reward = rew; o.dmin = dmin; o.done = (uint8_t)dn; o.info = (uint8_t)inf; o.reserved = 0; o.hh_count = hh_sum;
+        p.out.rec[e] = o;                                // one 24-byte store
     }
     if (active && p.out.human_act)
         reinterpret_cast<double2 *>(p.out.human_act)[a] = make_double2(hax, hay);
@@ -301,26 +298,23 @@ void env_step_kernel(const StepParams p)
     if (leader) {
         if (p.has_roll) {
             const mcn_rollout &r = p.roll;
-            if (inf == MCN_INFO_DANGER && r.danger_count) {
-                r.danger_count[e] += 1;
-                if (r.danger_dist_sum) r.danger_dist_sum[e] += dmin;
-            }
-            if (r.ep_return) {
-                const int t = ep_t;
-                const double ret = ep_ret + ep_disc * rew;
+            if (r.state) {
+                if (inf == MCN_INFO_DANGER) { rs.danger_count += 1; rs.danger_dist_sum += dmin; }
+                const double ret = rs.ep_return + ep_disc * rew;
                 if (dn) {
-                    const int k = ep_k;
+                    const int k = rs.fin_count;
                     // fin_slots == 1: keep the latest episode; otherwise keep the first fin_slots episodes
                     const bool keep = (r.fin_slots == 1) || (k < r.fin_slots);
                     const long rec = (long)(r.fin_slots == 1 ? 0 : k) * p.E + e;
                     if (keep && r.fin_return) r.fin_return[rec] = ret;
                     if (keep && r.fin_time)   r.fin_time[rec] = (inf == MCN_INFO_TIMEOUT) ? c.time_limit : t_new;
                     if (keep && r.fin_info)   r.fin_info[rec] = (uint8_t)inf;
-                    if (r.fin_count)  r.fin_count[e] = k + 1;
-                    r.ep_return[e] = 0; r.ep_steps[e] = 0;
+                    rs.fin_count = k + 1; rs.ep_return = 0; rs.ep_steps = 0;
+                    if (do_reset) rs.next_case = (next_case + r.case_stride) % r.pool_size;
                 } else {
-                    r.ep_return[e] = ret; r.ep_steps[e] = t + 1;
+                    rs.ep_return = ret; rs.ep_steps += 1;
                 }
+                r.state[e] = rs;                         // one 32-byte store
             }
         }
         if (do_reset && dn) {
@@ -329,7 +323,6 @@ void env_step_kernel(const StepParams p)
             reinterpret_cast<double2 *>(p.st.rvel)[e]  = make_double2(0, 0);
             if (p.st.rtheta) p.st.rtheta[e] = p.roll.robot_theta0;
             p.st.gtime[e] = 0;
-            if (p.roll.next_case) p.roll.next_case[e] = (next_case + p.roll.case_stride) % p.roll.pool_size;
         } else {
             reinterpret_cast<double2 *>(p.st.rpos)[e] = make_double2(endx, endy);
             reinterpret_cast<double2 *>(p.st.rvel)[e] = make_double2(nrvx, nrvy);

@@ -175,15 +175,14 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void env_step_quad_kernel(const S
         cvel = reinterpret_cast<const double2 *>(p.st.rvel)[eb];
         crd = rrad;
     }
-    int next_case = 0, ep_t = 0, ep_k = 0;
-    double ep_ret = 0, ep_disc = 0;
+    int next_case = 0;
+    double ep_disc = 0;
+    mcn_roll_rec rs = {0, 0, 0, 0, 0, 0};
     if (lead && p.has_roll) {
-        if (p.roll.next_case) next_case = p.roll.next_case[e];
-        if (p.roll.ep_return) {
-            ep_t = p.roll.ep_steps[e];
-            ep_ret = p.roll.ep_return[e];
-            ep_disc = p.roll.disc_table[ep_t < p.roll.disc_len ? ep_t : p.roll.disc_len - 1];
-            ep_k = p.roll.fin_count ? p.roll.fin_count[e] : 0;
+        if (p.roll.state) {
+            rs = p.roll.state[e];                       // one 32-byte record
+            next_case = rs.next_case;
+            ep_disc = p.roll.disc_table[rs.ep_steps < p.roll.disc_len ? rs.ep_steps : p.roll.disc_len - 1];
         }
     }
 
@@ -315,11 +314,9 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void env_step_quad_kernel(const S
     else if (dmin < c.discomfort_dist)  { rew = (dmin - c.discomfort_dist) * c.discomfort_penalty_factor * dt; dn = 0; inf = MCN_INFO_DANGER; }
     else                                { rew = 0; dn = 0; inf = MCN_INFO_NOTHING; }
     if (lead) {
-        p.out.reward[e] = rew;
-        p.out.dmin[e] = dmin;
-        p.out.done[e] = (uint8_t)dn;
-        p.out.info[e] = (uint8_t)inf;
-        p.out.hh_count[e] = hh_sum;
+        mcn_step_rec o;
+        o.reward = rew; o.dmin = dmin; o.done = (uint8_t)dn; o.info = (uint8_t)inf; o.reserved = 0; o.hh_count = hh_sum;
+        p.out.rec[e] = o;                                // one 24-byte store
     }
     }   // do_pair
     if (SPLIT) {
@@ -363,23 +360,23 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void env_step_quad_kernel(const S
     if (lead) {
         if (p.has_roll) {
             const mcn_rollout &ro = p.roll;
-            if (inf == MCN_INFO_DANGER && ro.danger_count) {
-                ro.danger_count[e] += 1;
-                if (ro.danger_dist_sum) ro.danger_dist_sum[e] += dmin;
-            }
-            if (ro.ep_return) {
-                const double ret = ep_ret + ep_disc * rew;
+            if (ro.state) {
+                if (inf == MCN_INFO_DANGER) { rs.danger_count += 1; rs.danger_dist_sum += dmin; }
+                const double ret = rs.ep_return + ep_disc * rew;
                 if (dn) {
-                    const bool keep = (ro.fin_slots == 1) || (ep_k < ro.fin_slots);
-                    const long rec = (long)(ro.fin_slots == 1 ? 0 : ep_k) * p.E + e;
+                    const int k = rs.fin_count;
+                    // fin_slots == 1: keep the latest episode; otherwise keep the first fin_slots episodes
+                    const bool keep = (ro.fin_slots == 1) || (k < ro.fin_slots);
+                    const long rec = (long)(ro.fin_slots == 1 ? 0 : k) * p.E + e;
                     if (keep && ro.fin_return) ro.fin_return[rec] = ret;
                     if (keep && ro.fin_time)   ro.fin_time[rec] = (inf == MCN_INFO_TIMEOUT) ? c.time_limit : t_new;
                     if (keep && ro.fin_info)   ro.fin_info[rec] = (uint8_t)inf;
-                    if (ro.fin_count)  ro.fin_count[e] = ep_k + 1;
-                    ro.ep_return[e] = 0; ro.ep_steps[e] = 0;
+                    rs.fin_count = k + 1; rs.ep_return = 0; rs.ep_steps = 0;
+                    if (do_reset) rs.next_case = (next_case + ro.case_stride) % ro.pool_size;
                 } else {
-                    ro.ep_return[e] = ret; ro.ep_steps[e] = ep_t + 1;
+                    rs.ep_return = ret; rs.ep_steps += 1;
                 }
+                ro.state[e] = rs;                         // one 32-byte store
             }
         }
         if (do_reset && dn) {
@@ -388,7 +385,6 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void env_step_quad_kernel(const S
             reinterpret_cast<double2 *>(p.st.rvel)[e]  = make_double2(0, 0);
             if (p.st.rtheta) p.st.rtheta[e] = p.roll.robot_theta0;
             p.st.gtime[e] = 0;
-            if (p.roll.next_case) p.roll.next_case[e] = (next_case + p.roll.case_stride) % p.roll.pool_size;
         } else {
             reinterpret_cast<double2 *>(p.st.rpos)[e] = make_double2(endx, endy);
             reinterpret_cast<double2 *>(p.st.rvel)[e] = make_double2(nrvx, nrvy);

@@ -36,15 +36,15 @@ int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *
     if (!st->hpos || !st->hvel || !st->hgoal || !st->hrad || !st->hvpref || !st->rpos || !st->rvel || !st->rgoal ||
         !st->rrad || !st->gtime) return MCN_EINVAL;
     if (cfg->robot_kinematics == MCN_KIN_UNICYCLE && !st->rtheta) return MCN_EINVAL;
-    if (!out->reward || !out->dmin || !out->done || !out->info || !out->hh_count) return MCN_EINVAL;
+    if (!out->rec) return MCN_EINVAL;
     if (!update && (!out->nobs_pos || !out->nobs_vel)) return MCN_EINVAL;
     if (cfg->human_policy == MCN_HUMANS_GIVEN && !given_v) return MCN_EINVAL;
     if (cfg->human_policy < MCN_HUMANS_ORCA || cfg->human_policy > MCN_HUMANS_GIVEN) return MCN_EINVAL;
     if (cfg->orca_max_neighbors < 0 || cfg->orca_max_neighbors > MCN_MAX_LINES) return MCN_EINVAL;
     if (!(cfg->time_step > 0)) return MCN_EINVAL;
     if (roll) {
-        if (roll->ep_return && (!roll->ep_steps || !roll->disc_table || roll->disc_len <= 0)) return MCN_EINVAL;
-        if (roll->ep_return && roll->fin_slots < 1) return MCN_EINVAL;
+        if (roll->state && (!roll->disc_table || roll->disc_len <= 0 || roll->fin_slots < 1)) return MCN_EINVAL;
+        if (roll->pool_hpos && !roll->state) return MCN_EINVAL;
         if (roll->pool_hpos && (!roll->pool_hgoal || !roll->pool_hrad || !roll->pool_hvpref || roll->pool_size <= 0)) return MCN_EINVAL;
     }
     mcn::StepParams p;

@@ -120,19 +120,19 @@ class VecCrowdSim(object):
         self.rrad, self.rvpref = z(E), z(E)
         self.rtheta, self.gtime = z(E), z(E)
         self.human_times = z(E, N)
-        self.reward, self.dmin = z(E), z(E)
-        self.done, self.info = z(E, dtype=torch.uint8), z(E, dtype=torch.uint8)
-        self.hh_count = z(E, dtype=torch.int32)
+        # per-step outputs are one 24-byte record per env (mcn_step_rec); the named fields are strided views of it
+        self.step_rec = z(E, 3)
+        v = _hip.step_rec_views(self.step_rec)
+        self.reward, self.dmin, self.done, self.info, self.hh_count = (v[k] for k in
+                                                                       ("reward", "dmin", "done", "info", "hh_count"))
         self.human_act = z(E, N, 2)
         self.nobs_pos, self.nobs_vel = z(E, N, 2), z(E, N, 2)
         self._alloc_N = N
         self._st = _hip.EnvState(*[_hip.ptr(t) for t in (self.hpos, self.hvel, self.hgoal, self.hrad, self.hvpref,
                                                          self.rpos, self.rvel, self.rgoal, self.rrad, self.rvpref,
                                                          self.rtheta, self.gtime, self.human_times)])
-        self._out = _hip.EnvOut(*[_hip.ptr(t) for t in (self.reward, self.dmin, self.done, self.info, self.hh_count,
-                                                        self.human_act, self.nobs_pos, self.nobs_vel)])
-        self._out_lean = _hip.EnvOut(*[_hip.ptr(t) for t in (self.reward, self.dmin, self.done, self.info,
-                                                             self.hh_count, None, self.nobs_pos, self.nobs_vel)])
+        self._out = _hip.EnvOut(*[_hip.ptr(t) for t in (self.step_rec, self.human_act, self.nobs_pos, self.nobs_vel)])
+        self._out_lean = _hip.EnvOut(*[_hip.ptr(t) for t in (self.step_rec, None, self.nobs_pos, self.nobs_vel)])
 
     def _cfg_struct(self, human_policy=None):
         hp = {"orca": _hip.HUMANS_ORCA, "linear": _hip.HUMANS_LINEAR, "given": _hip.HUMANS_GIVEN}[
@@ -264,18 +264,15 @@ class VecCrowdSim(object):
         disc = np.array([pow(gamma, t * self.time_step * v_pref) for t in range(horizon)], np.float64)
         t = {}
         t["disc"] = torch.from_numpy(disc).to(dev)
-        t["ep_return"] = torch.zeros(E, dtype=torch.float64, device=dev)
-        t["ep_steps"] = torch.zeros(E, dtype=torch.int32, device=dev)
+        # per-env rollout state is one 32-byte record (mcn_roll_rec); the named entries are strided views of it
+        t["state"] = torch.zeros(E, 4, dtype=torch.float64, device=dev)
+        t.update(_hip.roll_rec_views(t["state"]))
         t["fin_return"] = torch.zeros(fin_slots, E, dtype=torch.float64, device=dev)
         t["fin_time"] = torch.zeros(fin_slots, E, dtype=torch.float64, device=dev)
         t["fin_info"] = torch.zeros(fin_slots, E, dtype=torch.uint8, device=dev)
-        t["fin_count"] = torch.zeros(E, dtype=torch.int32, device=dev)
-        t["danger_count"] = torch.zeros(E, dtype=torch.int32, device=dev)
-        t["danger_dist_sum"] = torch.zeros(E, dtype=torch.float64, device=dev)
         r = _hip.Rollout()
         r.disc_table, r.disc_len, r.fin_slots = _hip.ptr(t["disc"]), horizon, int(fin_slots)
-        for k in ("ep_return", "ep_steps", "fin_return", "fin_time", "fin_info", "fin_count", "danger_count",
-                  "danger_dist_sum"):
+        for k in ("state", "fin_return", "fin_time", "fin_info"):
             setattr(r, k, _hip.ptr(t[k]))
         if pool is not None:
             pool = np.asarray(pool, np.float64)
@@ -287,11 +284,11 @@ class VecCrowdSim(object):
             t["pool_hrad"] = up(pool[:, :, S.RAD]); t["pool_hvpref"] = up(pool[:, :, S.VPREF])
             t["pool_hvel"] = up(pool[:, :, [S.VX, S.VY]])
             nc = np.arange(E) % P if first_cases is None else np.asarray(first_cases) % P
-            t["next_case"] = torch.from_numpy(nc.astype(np.int32)).to(dev)
+            t["next_case"].copy_(torch.from_numpy(nc.astype(np.int32)).to(dev))
             r.pool_hpos, r.pool_hgoal = _hip.ptr(t["pool_hpos"]), _hip.ptr(t["pool_hgoal"])
             r.pool_hrad, r.pool_hvpref = _hip.ptr(t["pool_hrad"]), _hip.ptr(t["pool_hvpref"])
             r.pool_hvel = _hip.ptr(t["pool_hvel"])
-            r.pool_size, r.next_case, r.case_stride = P, _hip.ptr(t["next_case"]), int(case_stride)
+            r.pool_size, r.case_stride = P, int(case_stride)
             rr = self.spec().robot_row()
             r.robot_start[0], r.robot_start[1] = rr[S.PX], rr[S.PY]
             r.robot_goal[0], r.robot_goal[1] = rr[S.GX], rr[S.GY]

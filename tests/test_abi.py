@@ -28,11 +28,33 @@ def test_struct_sizes_match_header():
     from modelcrowdnav_amd import _hip
     assert ctypes.sizeof(_hip.EnvCfg) == 7 * 8 + 2 * 4 + 6 * 4
     assert ctypes.sizeof(_hip.EnvState) == 13 * 8
-    assert ctypes.sizeof(_hip.EnvOut) == 8 * 8
+    assert ctypes.sizeof(_hip.EnvOut) == 4 * 8
+    assert ctypes.sizeof(_hip.StepRec) == 24 and _hip.StepRec.done.offset == 16 and _hip.StepRec.hh_count.offset == 20
+    assert ctypes.sizeof(_hip.RollRec) == 32 and _hip.RollRec.fin_count.offset == 12
+    assert _hip.RollRec.danger_dist_sum.offset == 24
     r = _hip.Rollout
-    assert r.disc_len.offset == 8 and r.ep_return.offset == 16 and r.fin_slots.offset == 64
-    assert r.danger_count.offset == 72 and r.pool_hpos.offset == 88 and r.pool_size.offset == 128
-    assert r.robot_start.offset % 8 == 0
+    assert r.disc_len.offset == 8 and r.state.offset == 16 and r.fin_slots.offset == 48
+    assert r.pool_hpos.offset == 56 and r.pool_size.offset == 96 and r.case_stride.offset == 100
+    assert r.robot_start.offset == 104 and ctypes.sizeof(r) == 144
+
+
+def test_record_views_alias_the_packed_records():
+    """The named per-env tensors are strided views of mcn_step_rec / mcn_roll_rec arrays."""
+    import numpy as np
+    import torch
+    from modelcrowdnav_amd import _hip
+    raw = np.zeros(5, dtype=np.dtype([("reward", "f8"), ("dmin", "f8"), ("done", "u1"), ("info", "u1"),
+                                      ("pad", "u2"), ("hh", "i4")]))
+    raw["reward"], raw["dmin"], raw["done"], raw["info"], raw["hh"] = np.arange(5), -np.arange(5), 1, [0, 1, 2, 3, 4], 7
+    v = _hip.step_rec_views(torch.from_numpy(raw.view(np.float64).reshape(5, 3).copy()))
+    assert v["reward"].tolist() == [0, 1, 2, 3, 4] and v["dmin"][2] == -2 and v["done"].tolist() == [1] * 5
+    assert v["info"].tolist() == [0, 1, 2, 3, 4] and v["hh_count"].tolist() == [7] * 5
+    rr = np.zeros(3, dtype=np.dtype([("ret", "f8"), ("steps", "i4"), ("fin", "i4"), ("case", "i4"), ("dc", "i4"),
+                                     ("dsum", "f8")]))
+    rr["ret"], rr["steps"], rr["fin"], rr["case"], rr["dc"], rr["dsum"] = 0.5, 3, 4, [9, 8, 7], 2, 1.25
+    w = _hip.roll_rec_views(torch.from_numpy(rr.view(np.float64).reshape(3, 4).copy()))
+    assert w["ep_return"].tolist() == [0.5] * 3 and w["ep_steps"].tolist() == [3] * 3 and w["fin_count"][1] == 4
+    assert w["next_case"].tolist() == [9, 8, 7] and w["danger_count"][0] == 2 and w["danger_dist_sum"][2] == 1.25
 
 
 def test_bad_arguments_are_rejected_on_host():

@@ -36,7 +36,9 @@ def main():
         acts = bench.make_actions(16, E, E, 0, dev)
         gv = torch.rand(E, N, 2, dtype=torch.float64, device=dev) - 0.5
         for mode in a.modes.split(","):
-            g = gv if mode == "given" else None
+            g = gv if mode.startswith("given") else None
+            if mode.endswith("-noroll"):
+                env.detach_rollout()        # no Explorer bookkeeping / auto-reset: fewer per-env streams
             for t in range(8):
                 env.step(acts[t], given_v=g)
             torch.cuda.synchronize()
@@ -49,8 +51,8 @@ def main():
             for rep in range(3):
                 s.record(); graph.replay(); e.record(); torch.cuda.synchronize()
                 best = min(best, s.elapsed_time(e) / a.iters)
-            nb = bench.pairwise_bytes_per_env_step(N) if mode == "given" else bench.algorithmic_bytes_per_env_step(N)
-            print("N=%d E=%8d mode=%-5s  %9.2f us/launch  %8.1f M env-steps/s  %7.1f GB/s (%.1f%% of 8 TB/s)" % (
+            nb = bench.pairwise_bytes_per_env_step(N) if mode.startswith("given") else bench.algorithmic_bytes_per_env_step(N)
+            print("N=%d E=%8d mode=%-12s  %9.2f us/launch  %8.1f M env-steps/s  %7.1f GB/s (%.1f%% of 8 TB/s)" % (
                 N, E, mode, best * 1e3, E / best / 1e3, nb * E / best / 1e6, nb * E / best / 1e6 / 80.0))
         del env
 

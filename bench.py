@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--humans", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--steps-per-launch", type=int, default=50,
+                    help="env steps handed to one mcn_env_rollout call (the action sequence is known up front); "
+                         "1 = one mcn_env_step launch per step")
     ap.add_argument("--sweep", type=str, default="65536,1048576,4194304", help="extra batch sizes for roofline_sweep")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -121,7 +124,7 @@ def pairwise_bytes_per_env_step(N):
 _PMC = None
 
 
-def pmc_traffic(E, given):
+def pmc_traffic(E, given, steps_per_launch=1):
     """HBM bytes per launch from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     passes, gfx950 FETCH_SIZE x2 correction; profiles/r01_pmc_env_step.json).  None where no such run exists."""
     global _PMC
@@ -131,17 +134,21 @@ def pmc_traffic(E, given):
         except Exception:
             _PMC = []
     for k in _PMC:
-        if k["envs"] == E and ("pairwise-only" in k["what"]) == bool(given):
+        if k["envs"] == E and ("pairwise-only" in k["what"]) == bool(given) and k.get("steps_per_launch", 1) == steps_per_launch:
             return k["traffic_bytes_per_launch"]
     return None
 
 
-def roofline_entry(E, N, avg_ms, extra=None, given=False):
-    by = (pairwise_bytes_per_env_step(N) if given else algorithmic_bytes_per_env_step(N)) * E
+def roofline_entry(E, N, avg_ms, extra=None, given=False, steps_per_launch=1):
+    """avg_ms: average duration of ONE launch, which advances E envs by `steps_per_launch` steps."""
+    by = (pairwise_bytes_per_env_step(N) if given else algorithmic_bytes_per_env_step(N)) * E * steps_per_launch
     ach = by / (avg_ms * 1e-3) / 1e9
     d = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(E, given) if N == 5 else None,
-         "kernel": "mcn::env_step_kernel", "envs_per_launch": E, "algorithmic_bytes_per_launch": by,
+         "frac": round(ach / HBM_PEAK_GBS, 5),
+         "traffic": pmc_traffic(E, given, steps_per_launch) if N == 5 else None,
+         "kernel": "mcn::env_step_kernel" if steps_per_launch == 1 else "mcn::env_rollout_quad_kernel",
+         "envs_per_launch": E, "env_steps_per_launch": int(round(E * steps_per_launch)),
+         "algorithmic_bytes_per_launch": int(round(by)),
          "avg_launch_us": round(avg_ms * 1e3, 3)}
     if extra:
         d.update(extra)
@@ -286,9 +293,24 @@ def main():
     acts = make_actions(W + K, E, E_total, rank * E, device)
 
     # warm-up: W eager steps (also primes the allocator before capture)
-    for t in range(W):
+    for t in range(W if args.steps_per_launch <= 1 else min(W, 1)):
         env.step(acts[t])
+    if args.steps_per_launch > 1 and W > 1:
+        env.rollout(acts[1:W])
     torch.cuda.synchronize()
+
+    # the robot's actions are a pre-drawn random sequence, so S consecutive steps go to the device as one
+    # mcn_env_rollout call (state stays in registers between steps); S = 1 is one mcn_env_step launch per step
+    S = max(1, min(args.steps_per_launch, K))
+    chunks = [(t, min(S, K - t)) for t in range(0, K, S)]
+
+    def run_timed_steps():
+        if S == 1:
+            for t in range(K):
+                env.step(acts[W + t])
+        else:
+            for t, n in chunks:
+                env.rollout(acts[W + t:W + t + n])
 
     use_graph = not args.no_graph
     if use_graph:
@@ -296,8 +318,7 @@ def main():
         # RCCL watchdog thread polling events during stream capture is a known way to break a capture
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            for t in range(K):
-                env.step(acts[W + t])
+            run_timed_steps()
 
     rb = env.rollout_buffers
     gathered = None
@@ -324,8 +345,7 @@ def main():
     if use_graph:
         graph.replay()
     else:
-        for t in range(K):
-            env.step(acts[W + t])
+        run_timed_steps()
     ev_e.record()
     if world > 1:
         # the path's one exchange: episode returns + outcome codes + counts, one fused buffer, one collective
@@ -338,14 +358,19 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     # dominant-kernel duration: HIP events (launch stream) bracketing the K back-to-back launches of the timed region
-    kernel_ms = ev_s.elapsed_time(ev_e) / K
+    n_launch = K if S == 1 else len(chunks)
+    kernel_ms = ev_s.elapsed_time(ev_e) / n_launch
 
     rb = env.rollout_buffers
     episodes = int(rb["fin_count"].sum().item())
     mean_ret = float(rb["fin_return"][0][rb["fin_count"] > 0].mean().item()) if episodes else float("nan")
 
     roof = roofline_entry(E, N, kernel_ms, {"timing": "HIP events around the %d launches of the timed region (%s)" % (
-        K, "one hipGraph" if use_graph else "eager")})
+        n_launch, "one hipGraph" if use_graph else "eager")}, steps_per_launch=K / n_launch)
+    if S > 1:
+        # state lives in registers across the steps of a launch: HBM sees the state once per launch, not per step
+        roof["note"] = ("algorithmic bytes = SURVEY 8(d) per-env-step figure x env-steps per launch; a launch keeps the "
+                        "env state in registers for its %d steps, so real HBM traffic is ~1/%d of that" % (S, S))
 
     result = {
         "metric": "env-steps/sec (whole node), 5-human CrowdSim x batched envs",
@@ -354,13 +379,21 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "%d envs x %d humans per GPU, ORCA humans, random robot actions (81-entry table), "
-                               "auto-reset, 1 mcn_env_step launch per step" % (E, N),
+                               "auto-reset, %s" % (E, N, "1 mcn_env_step launch per step" if S == 1 else
+                                                   "%d steps per mcn_env_rollout launch" % S),
+                   "steps_per_launch": S,
                    "envs_per_gpu": E, "humans": N, "launch": "hipGraph" if use_graph else "eager",
                    "parallelism": "env-shard x%d, no per-step collective" % world},
         "episodes_finished": episodes, "mean_discounted_return": round(mean_ret, 6),
         "gathered_episode_records": None if gathered is None else int((gathered[:, 2] > 0).sum().item()),
         "roofline": roof,
     }
+
+    if rank == 0 and world == 1 and S > 1:
+        # the same workload stepped one mcn_env_step launch at a time (policy-in-the-loop callers pay this)
+        one_ms, _ = time_kernel_events(env, acts, 200)
+        result["single_step_launch"] = roofline_entry(E, N, one_ms, {
+            "mode": "one mcn_env_step launch per step, hipGraph of 200", "env_steps_per_sec": round(E / (one_ms * 1e-3), 1)})
 
     if rank == 0 and world == 1 and not args.no_sweep:
         sweep = []

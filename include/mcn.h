@@ -142,6 +142,18 @@ int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *
                  int32_t E, int32_t N, int32_t update, void *stream);
 
 /*
+ * mcn_env_rollout -- T consecutive mcn_env_step(update = 1) calls with the action sequence actions[T][E][2],
+ * same results bit for bit.  Replaces the step loop of Explorer.run_k_episodes (crowd_nav/utils/explorer.py:69-99)
+ * for robots whose actions do not depend on the observation (random / scripted sequences).  Where the batch is
+ * small enough to be latency-bound and every human has <= 4 ORCA neighbours, the T steps run in ONE launch with
+ * the env state held in registers; otherwise this is T launches.  On return `st` is the state after step T,
+ * `out->rec` / `out->human_act` are those of step T, `roll` has accounted for all T steps (episodes that end
+ * inside the sequence are recorded and, with a pool, restarted in-kernel).  Humans: ORCA or linear (no given_v).
+ */
+int mcn_env_rollout(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *actions, int32_t T,
+                    const mcn_env_out *out, const mcn_rollout *roll, int32_t E, int32_t N, void *stream);
+
+/*
  * mcn_orca_batch -- ORCA velocity for B independent agents, each with up to M candidate
  * neighbours (float32, RVO2 semantics).  Replaces the rvo2.PyRVOSimulator
  * addAgent / setAgent... / doStep / getAgentVelocity(0) sequence of orca.py:95-129 for arbitrary agents

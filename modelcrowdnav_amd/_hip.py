@@ -92,6 +92,9 @@ def _load():
     lib.mcn_env_step.argtypes = [C.POINTER(EnvCfg), C.POINTER(EnvState), _vp, _vp, C.POINTER(EnvOut),
                                  C.POINTER(Rollout), _i, _i, _i, _vp]
     lib.mcn_env_step.restype = C.c_int
+    lib.mcn_env_rollout.argtypes = [C.POINTER(EnvCfg), C.POINTER(EnvState), _vp, _i, C.POINTER(EnvOut),
+                                    C.POINTER(Rollout), _i, _i, _vp]
+    lib.mcn_env_rollout.restype = C.c_int
     lib.mcn_orca_batch.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _f, _f, _vp]
     lib.mcn_orca_batch.restype = C.c_int
     fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
@@ -112,7 +115,7 @@ def _load():
 lib = _load()
 
 # every symbol include/mcn.h declares; tests/test_abi.py checks the .so exports each one
-EXPORTED = ["mcn_version", "mcn_env_step", "mcn_orca_batch", "mcn_pack_linear", "mcn_sarl_workspace_bytes",
+EXPORTED = ["mcn_version", "mcn_env_step", "mcn_env_rollout", "mcn_orca_batch", "mcn_pack_linear", "mcn_sarl_workspace_bytes",
             "mcn_sarl_lookahead", "mcn_sgan_workspace_bytes", "mcn_sgan_step"]
 
 

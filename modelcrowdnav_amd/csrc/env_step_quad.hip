@@ -20,106 +20,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/mcn.h"
-#include "orca_device.hpp"
-#include "orca_static.hpp"
+#include "quad_common.hpp"
 #include "env_step_params.hpp"
 #include "env_common.hpp"
 
 namespace mcn {
-
-// quad broadcast of lane I (0..3) of every quad: a DPP move, no LDS traffic
-template <int I>
-__device__ __forceinline__ int qbi(int v) { return __builtin_amdgcn_update_dpp(0, v, I * 0x55, 0xf, 0xf, false); }
-template <int I>
-__device__ __forceinline__ float qbf(float v) { return __builtin_bit_cast(float, qbi<I>(__builtin_bit_cast(int, v))); }
-template <int I>
-__device__ __forceinline__ double qbd(double v)
-{
-    const long long b = __builtin_bit_cast(long long, v);
-    const int lo = qbi<I>((int)b), hi = qbi<I>((int)(b >> 32));
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-template <int I>
-__device__ __forceinline__ float4 qb4(float4 v) { return make_float4(qbf<I>(v.x), qbf<I>(v.y), qbf<I>(v.z), qbf<I>(v.w)); }
-
-__device__ __forceinline__ float4 sel4(const float4 (&L)[4], int i)
-{
-    const float4 a = i == 1 ? L[1] : L[0], b = i == 3 ? L[3] : L[2];
-    return i >= 2 ? b : a;
-}
-
-// linearProgram1 on line `no` (run-time, 0..3) against lines [0, no): uniform code, predicated steps.
-template <bool DIR>
-__device__ __forceinline__ bool lp1_rt(const float4 (&L)[4], int no, float radius, float optx, float opty, float &rx, float &ry)
-{
-    const float4 ln = sel4(L, no);
-    const float dp = dot2(ln.x, ln.y, ln.z, ln.w);
-    const float disc = dp * dp + radius * radius - dot2(ln.x, ln.y, ln.x, ln.y);
-    bool ok = !(disc < 0.0f);
-    const float sq = sqrtf(disc);
-    float tl = -dp - sq;
-    float tr = -dp + sq;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        if (i < no) {
-            const float4 li = L[i];
-            const float den = det2(ln.z, ln.w, li.z, li.w);
-            const float num = det2(li.z, li.w, ln.x - li.x, ln.y - li.y);
-            if (fabsf(den) <= kRvoEps) {
-                if (num < 0.0f) ok = false;
-            } else {
-                const float t = num / den;
-                if (den >= 0.0f) tr = fminf(tr, t);
-                else             tl = fmaxf(tl, t);
-                if (tl > tr) ok = false;
-            }
-        }
-    }
-    float t;
-    if (DIR) {
-        t = (dot2(optx, opty, ln.z, ln.w) > 0.0f) ? tr : tl;
-    } else {
-        t = dot2(ln.z, ln.w, optx - ln.x, opty - ln.y);
-        if (t < tl) t = tl; else if (t > tr) t = tr;
-    }
-    rx = ln.x + t * ln.z;
-    ry = ln.y + t * ln.w;
-    return ok;
-}
-
-// 3-D LP candidate of line `no` (run-time): project lines [0,no) on it, direction-optimising 2-D LP.
-__device__ __forceinline__ bool lp3_candidate(const float4 (&L)[4], int no, float radius, float &rx, float &ry)
-{
-    const float4 li = sel4(L, no);
-    float4 P[3];
-    int m = 0;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const float4 lj = L[j];
-        const float dt = det2(li.z, li.w, lj.z, lj.w);
-        float qx, qy;
-        bool skip = !(j < no);
-        if (fabsf(dt) <= kRvoEps) {
-            if (dot2(li.z, li.w, lj.z, lj.w) > 0.0f) skip = true;
-            qx = 0.5f * (li.x + lj.x); qy = 0.5f * (li.y + lj.y);
-        } else {
-            const float sc = det2(lj.z, lj.w, li.x - lj.x, li.y - lj.y) / dt;
-            qx = li.x + sc * li.z; qy = li.y + sc * li.w;
-        }
-        const float ddx = lj.z - li.z, ddy = lj.w - li.w;
-        const float inv = 1.0f / sqrtf(dot2(ddx, ddy, ddx, ddy));
-        const float4 q = make_float4(qx, qy, ddx * inv, ddy * inv);
-#pragma unroll
-        for (int sl = 0; sl < 3; ++sl)
-            if (!skip && sl == m) P[sl] = q;
-        m += skip ? 0 : 1;
-    }
-    const float ox = -li.w, oy = li.z;
-    rx = radius * ox; ry = radius * oy;
-    int fail = m;
-    Lp2Step<0, 3, true>::run(P, m, radius, ox, oy, rx, ry, fail);
-    return fail == m;
-}
 
 // SPLIT = true: the workgroup has two wavefronts working on the same G envs.  Wavefront 0 solves ORCA (float32),
 // wavefront 1 does the float64 swept-circle / overlap tests, the reward ladder and all per-env outputs AT THE
@@ -189,75 +94,9 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void env_step_quad_kernel(const S
     // ---- K1: ORCA, one half-plane per lane ----
     double hax = 0, hay = 0;
     if (do_orca) {
-    const float fpx = (float)pos.x, fpy = (float)pos.y, fvx = (float)vel.x, fvy = (float)vel.y;
-    const float frad = (float)(rad + 0.01 + c.orca_safety_space);
-    const float ms = (float)vpref;
-    const float prefx = (float)(goal.x - pos.x), prefy = (float)(goal.y - pos.y);
-    const float4 o = make_float4((float)cpos.x, (float)cpos.y, (float)cvel.x, (float)cvel.y);
-    const float orad = (float)(crd + 0.01 + c.orca_safety_space);
-    const float range_sq = c.orca_neighbor_dist * c.orca_neighbor_dist;
-    const float ddx = fpx - o.x, ddy = fpy - o.y;
-    const float d = dot2(ddx, ddy, ddx, ddy);
-    const int in = ((cand_h || cand_r) && (d < range_sq)) ? 1 : 0;
-    const float d0 = qbf<0>(d), d1 = qbf<1>(d), d2 = qbf<2>(d), d3 = qbf<3>(d);
-    const int i0 = qbi<0>(in), i1 = qbi<1>(in), i2 = qbi<2>(in), i3 = qbi<3>(in);
-    const int nin = i0 + i1 + i2 + i3;
-    int rank;
-    if (in) {        // stable ascending order among the in-range candidates (RVO2 insertAgentNeighbor)
-        rank = (i0 && (d0 < d || (d0 == d && 0 < k))) + (i1 && (d1 < d || (d1 == d && 1 < k))) +
-               (i2 && (d2 < d || (d2 == d && 2 < k))) + (i3 && (d3 < d || (d3 == d && 3 < k)));
-    } else {         // the rest fill the remaining slots in lane order so that ranks stay a permutation
-        rank = nin + ((0 < k && !i0) ? 1 : 0) + ((1 < k && !i1) ? 1 : 0) + ((2 < k && !i2) ? 1 : 0);
-    }
-    int nl = nin < c.orca_max_neighbors ? nin : c.orca_max_neighbors;
-    const float inv_th = 1.0f / c.orca_time_horizon;
-    const float inv_ts = 1.0f / (float)dt;
-    const float4 mine = orca_line_merged(fpx, fpy, fvx, fvy, frad, o, orad, inv_th, inv_ts);
-    // route my half-plane to lane `rank` of the quad, then share all four
-    const int dst = ((lane & ~3) | rank) << 2;
-    float4 srt;
-    srt.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dst, __builtin_bit_cast(int, mine.x)));
-    srt.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dst, __builtin_bit_cast(int, mine.y)));
-    srt.z = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dst, __builtin_bit_cast(int, mine.z)));
-    srt.w = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dst, __builtin_bit_cast(int, mine.w)));
-    const float4 L[4] = {qb4<0>(srt), qb4<1>(srt), qb4<2>(srt), qb4<3>(srt)};
-
-    // speculative 1-D LPs, one per lane; then the incremental LP is four compare-and-take steps
-    float cx, cy;
-    const int okm = lp1_rt<false>(L, k, ms, prefx, prefy, cx, cy) ? 1 : 0;
     float rx, ry;
-    if (dot2(prefx, prefy, prefx, prefy) > ms * ms) {
-        const float inv = 1.0f / sqrtf(dot2(prefx, prefy, prefx, prefy));
-        rx = ms * (prefx * inv); ry = ms * (prefy * inv);
-    } else {
-        rx = prefx; ry = prefy;
-    }
-    int fail = nl;
-#define MCN_LP2_TAKE(I)                                                                        \
-    {                                                                                          \
-        const int ok_i = qbi<I>(okm); const float cx_i = qbf<I>(cx), cy_i = qbf<I>(cy);        \
-        if (I < nl && fail == nl && det2(L[I].z, L[I].w, L[I].x - rx, L[I].y - ry) > 0.0f) {   \
-            if (ok_i) { rx = cx_i; ry = cy_i; } else fail = I;                                  \
-        }                                                                                      \
-    }
-    MCN_LP2_TAKE(0) MCN_LP2_TAKE(1) MCN_LP2_TAKE(2) MCN_LP2_TAKE(3)
-#undef MCN_LP2_TAKE
-    if (__any(fail < nl)) {
-        // dense crowd: 3-D LP.  Candidates of all four lines in parallel, combined in line order.
-        float c3x, c3y;
-        const int ok3 = lp3_candidate(L, k, ms, c3x, c3y) ? 1 : 0;
-        float dist = 0.0f;
-#define MCN_LP3_TAKE(I)                                                                        \
-    {                                                                                          \
-        const int ok_i = qbi<I>(ok3); const float cx_i = qbf<I>(c3x), cy_i = qbf<I>(c3y);      \
-        if (fail < nl && I >= fail && I < nl && det2(L[I].z, L[I].w, L[I].x - rx, L[I].y - ry) > dist) { \
-            if (ok_i) { rx = cx_i; ry = cy_i; }                                                 \
-            dist = det2(L[I].z, L[I].w, L[I].x - rx, L[I].y - ry);                             \
-        }                                                                                      \
-    }
-        MCN_LP3_TAKE(0) MCN_LP3_TAKE(1) MCN_LP3_TAKE(2) MCN_LP3_TAKE(3)
-#undef MCN_LP3_TAKE
-    }
+    quad_orca_velocity(c, lane, k, cand_h || cand_r, pos, vel, goal, rad, vpref,
+                       make_float4((float)cpos.x, (float)cpos.y, (float)cvel.x, (float)cvel.y), crd, dt, rx, ry);
     hax = (double)rx; hay = (double)ry;
     }
 

@@ -10,6 +10,7 @@
 
 namespace mcn {
 int launch_env_step(const StepParams &p, hipStream_t stream);
+bool launch_env_rollout_quad(const StepParams &p, int T, hipStream_t stream);
 struct SarlParams;
 long sarl_workspace_float4s(int E, int N, int A);
 int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int A, double dt,
@@ -23,13 +24,10 @@ int launch_orca_batch(const float *self, const float *others, const int32_t *n_o
                       hipStream_t stream);
 }  // namespace mcn
 
-extern "C" {
-
-const char *mcn_version(void) { return "modelcrowdnav_amd 0.1 (gfx950)"; }
-
-int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *actions,
-                 const double *given_v, const mcn_env_out *out, const mcn_rollout *roll,
-                 int32_t E, int32_t N, int32_t update, void *stream)
+// Validates one env-step problem and fills the kernel argument block.  Shared by mcn_env_step / mcn_env_rollout.
+static int fill_step_params(mcn::StepParams &p, const mcn_env_cfg *cfg, const mcn_env_state *st, const double *actions,
+                            const double *given_v, const mcn_env_out *out, const mcn_rollout *roll,
+                            int32_t E, int32_t N, int32_t update)
 {
     if (!cfg || !st || !out || !actions) return MCN_EINVAL;
     if (E <= 0 || N <= 0 || N > MCN_MAX_HUMANS) return MCN_EINVAL;
@@ -47,7 +45,6 @@ int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *
         if (roll->pool_hpos && !roll->state) return MCN_EINVAL;
         if (roll->pool_hpos && (!roll->pool_hgoal || !roll->pool_hrad || !roll->pool_hvpref || roll->pool_size <= 0)) return MCN_EINVAL;
     }
-    mcn::StepParams p;
     memset(&p, 0, sizeof(p));
     p.cfg = *cfg; p.st = *st; p.out = *out;
     if (roll) { p.roll = *roll; p.has_roll = 1; }
@@ -57,24 +54,58 @@ int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *
     int nl = ncand < cfg->orca_max_neighbors ? ncand : cfg->orca_max_neighbors;
     if (cfg->human_policy != MCN_HUMANS_ORCA) nl = 0;
     p.nl_cap = nl;
-    {
-        // Small batches are latency-bound: use the quad-parallel kernel (env_step_quad.hip) while its 4x wider
-        // grid still fits the chip about twice over (measured cross-over on MI355X: ~2800 wavefronts, i.e.
-        // E <= 8192 at 5 humans); above that the lane-per-human kernel wins on throughput.  Inside the quad
-        // kernel, ORCA and the float64 pairwise work go to two cooperating wavefronts only while BOTH still get a
-        // SIMD of their own (grid <= 512 workgroups).  MCN_QUAD_MAX_ENVS / MCN_QUAD_SPLIT override (tests, tuning).
-        const char *env_gen = getenv("MCN_FORCE_GENERIC");
-        p.force_generic = env_gen ? atoi(env_gen) : 0;
-        const char *env_noop = getenv("MCN_DEBUG_NOOP");
-        p.debug_noop = env_noop ? atoi(env_noop) : 0;
-        const char *env_max = getenv("MCN_QUAD_MAX_ENVS");
-        const char *env_split = getenv("MCN_QUAD_SPLIT");
-        const int envs_per_wave = 64 / (4 * N);
-        const long quad_waves = envs_per_wave > 0 ? ((long)E + envs_per_wave - 1) / envs_per_wave : (1L << 40);
-        p.quad_max_envs = env_max ? atoi(env_max) : (quad_waves <= 2800 ? E : 0);
-        p.quad_split = env_split ? atoi(env_split) : (quad_waves <= 512 ? 1 : 0);
-    }
+    // Small batches are latency-bound: use the quad-parallel kernel (env_step_quad.hip) while its 4x wider
+    // grid still fits the chip about twice over (measured cross-over on MI355X: ~2800 wavefronts, i.e.
+    // E <= 8192 at 5 humans); above that the lane-per-human kernel wins on throughput.  Inside the quad
+    // kernel, ORCA and the float64 pairwise work go to two cooperating wavefronts only while BOTH still get a
+    // SIMD of their own (grid <= 512 workgroups).  MCN_QUAD_MAX_ENVS / MCN_QUAD_SPLIT override (tests, tuning).
+    const char *env_gen = getenv("MCN_FORCE_GENERIC");
+    p.force_generic = env_gen ? atoi(env_gen) : 0;
+    const char *env_noop = getenv("MCN_DEBUG_NOOP");
+    p.debug_noop = env_noop ? atoi(env_noop) : 0;
+    const char *env_max = getenv("MCN_QUAD_MAX_ENVS");
+    const char *env_split = getenv("MCN_QUAD_SPLIT");
+    const int envs_per_wave = 64 / (4 * N);
+    const long quad_waves = envs_per_wave > 0 ? ((long)E + envs_per_wave - 1) / envs_per_wave : (1L << 40);
+    p.quad_max_envs = env_max ? atoi(env_max) : (quad_waves <= 2800 ? E : 0);
+    p.quad_split = env_split ? atoi(env_split) : (quad_waves <= 512 ? 1 : 0);
+    return MCN_OK;
+}
+
+extern "C" {
+
+const char *mcn_version(void) { return "modelcrowdnav_amd 0.1 (gfx950)"; }
+
+int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *actions,
+                 const double *given_v, const mcn_env_out *out, const mcn_rollout *roll,
+                 int32_t E, int32_t N, int32_t update, void *stream)
+{
+    mcn::StepParams p;
+    const int rc = fill_step_params(p, cfg, st, actions, given_v, out, roll, E, N, update);
+    if (rc != MCN_OK) return rc;
     return mcn::launch_env_step(p, (hipStream_t)stream);
+}
+
+int mcn_env_rollout(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *actions, int32_t T,
+                    const mcn_env_out *out, const mcn_rollout *roll, int32_t E, int32_t N, void *stream)
+{
+    if (T <= 0) return MCN_EINVAL;
+    mcn::StepParams p;
+    const int rc = fill_step_params(p, cfg, st, actions, nullptr, out, roll, E, N, 1);
+    if (rc != MCN_OK) return rc;
+    // One launch with the env state held in registers for all T steps where the quad layout applies and the batch
+    // is still latency-bound (same cross-over as the single step); otherwise T single-step launches.
+    // MCN_ROLLOUT_FUSED=0/1 overrides (tests, tuning).
+    const char *env_fused = getenv("MCN_ROLLOUT_FUSED");
+    const bool fused = env_fused ? atoi(env_fused) != 0 : p.quad_max_envs >= E;
+    if (fused && !p.force_generic && mcn::launch_env_rollout_quad(p, T, (hipStream_t)stream))
+        return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
+    for (int32_t t = 0; t < T; ++t) {
+        p.actions = actions + (size_t)t * E * 2;
+        const int r = mcn::launch_env_step(p, (hipStream_t)stream);
+        if (r != MCN_OK) return r;
+    }
+    return MCN_OK;
 }
 
 int mcn_orca_batch(const float *self, const float *others, const int32_t *n_other, float *out,

@@ -234,6 +234,23 @@ class VecCrowdSim(object):
             ob = ObsBatch(self.nobs_pos, self.nobs_vel, self.hrad)
         return ob, self.reward, self.done, self.info
 
+    def rollout(self, actions):
+        """T consecutive step(update=True) calls for an action sequence known up front (actions: [T,E,2] float64
+        device tensor) -- the step loop of Explorer.run_k_episodes (explorer.py:69-99) for a robot that does not look
+        at the observation.  One mcn_env_rollout call: for small crowds the T steps are a single launch with the
+        state held in registers.  Results equal T step() calls bit for bit; the returned views are those of step T.
+        """
+        E, N = self.num_envs, self._alloc_N
+        if actions.dim() != 3 or tuple(actions.shape[1:]) != (E, 2):
+            raise ValueError("actions must be [T,E,2]")
+        if actions.dtype != torch.float64 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(self.device, torch.float64).contiguous()
+        rc = _hip.lib.mcn_env_rollout(self._cfg_struct(None), self._st, _hip.ptr(actions), int(actions.shape[0]),
+                                      self._out if self.export_human_actions else self._out_lean,
+                                      self._roll, E, N, _hip.stream_ptr(self.device))
+        _hip.check(rc, "mcn_env_rollout")
+        return self.observation(), self.reward, self.done, self.info
+
     def onestep_lookahead(self, actions):
         """crowd_sim.py:325-329: a non-mutating step; with look_ahead_in_sim the humans' next states come from the
         learned world model instead of ORCA (step_in_sim, crowd_sim.py:633-696)."""

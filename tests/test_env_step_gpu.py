@@ -175,6 +175,94 @@ def _rollout_4096x5():
     assert done_total > 0
 
 
+def _rollout_env(E, N, visible, with_pool, kinematics="holonomic", fin_slots=1):
+    from modelcrowdnav_amd.envs import scenarios as S
+    env = H.make_vec_env(E, N, robot_visible=visible, kinematics=kinematics)
+    pool = S.scenario_pool(env.spec(), "test", range(64), N, "circle_crossing")
+    ids = np.arange(E) % 64
+    env.load_scenarios(pool[ids])
+    env.attach_rollout(gamma=0.9, pool=pool if with_pool else None, case_stride=3, first_cases=(ids + 7) % 64,
+                       fin_slots=fin_slots)
+    return env
+
+
+def _snapshot(env):
+    c = lambda t: t.detach().cpu().numpy().copy()
+    snap = {k: c(getattr(env, k)) for k in ("hpos", "hvel", "hgoal", "hrad", "hvpref", "rpos", "rvel", "rgoal",
+                                            "rtheta", "gtime", "human_times", "step_rec", "human_act")}
+    snap.update({"roll_" + k: c(v) for k, v in env.rollout_buffers.items() if k in ("state", "fin_return", "fin_time",
+                                                                                  "fin_info")})
+    return snap
+
+
+@pytest.mark.parametrize("N,visible", [(5, False), (4, True), (3, False), (1, True), (2, False)])
+@pytest.mark.parametrize("with_pool", [True, False])
+def test_rollout_launch_equals_single_steps(N, visible, with_pool, monkeypatch):
+    """mcn_env_rollout (T steps in one launch, state in registers) == T mcn_env_step calls, every byte of state,
+    step record, Explorer accounting and finished-episode records; episodes end and restart inside the sequence."""
+    torch = _torch()
+    E, T = 1000, 110                    # ragged vs the envs-per-wavefront tiling; every env passes the time limit
+    rng = np.random.RandomState(N)
+    sp, aa = rng.uniform(0, 1, (T, E)), rng.uniform(0, 2 * np.pi, (T, E))
+    acts = torch.from_numpy(np.stack([sp * np.cos(aa), sp * np.sin(aa)], -1))
+    monkeypatch.setenv("MCN_ROLLOUT_FUSED", "1")
+    a = _rollout_env(E, N, visible, with_pool, fin_slots=2)
+    b = _rollout_env(E, N, visible, with_pool, fin_slots=2)
+    acts_d = acts.to(a.device)
+    a.rollout(acts_d[:30]); a.rollout(acts_d[30:31]); a.rollout(acts_d[31:])          # split launches compose
+    for t in range(T):
+        b.step(acts_d[t])
+    torch.cuda.synchronize()
+    sa, sb = _snapshot(a), _snapshot(b)
+    for k in sa:
+        assert np.array_equal(sa[k].view(np.uint8), sb[k].view(np.uint8)), k
+    assert int(a.rollout_buffers["fin_count"].min().item()) >= 1
+    monkeypatch.setenv("MCN_ROLLOUT_FUSED", "0")                # the T-launch path of the same entry point
+    c = _rollout_env(E, N, visible, with_pool, fin_slots=2)
+    c.rollout(acts_d)
+    torch.cuda.synchronize()
+    sc = _snapshot(c)
+    for k in sa:
+        assert np.array_equal(sc[k].view(np.uint8), sb[k].view(np.uint8)), k
+
+
+def test_rollout_launch_matches_oracle_trajectory():
+    """The fused T-step launch against the C oracle stepped T times (no pool: finished envs keep stepping, which the
+    oracle does too)."""
+    torch = _torch()
+    E, N, T = 513, 5, 40
+    env = H.make_vec_env(E, N)
+    env.reset("test", test_cases=[i % 500 for i in range(E)])
+    st = H.download(env)
+    cfg = H.oracle_cfg_for(env)
+    rng = np.random.RandomState(3)
+    sp, aa = rng.uniform(0, 1, (T, E)), rng.uniform(0, 2 * np.pi, (T, E))
+    ax, ay = sp * np.cos(aa), sp * np.sin(aa)
+    os.environ["MCN_ROLLOUT_FUSED"] = "1"
+    try:
+        env.rollout(torch.from_numpy(np.stack([ax, ay], -1)).to(env.device))
+    finally:
+        del os.environ["MCN_ROLLOUT_FUSED"]
+    for t in range(T):
+        ref = cport.env_step(cfg, st, ax[t], ay[t], update=True)
+    H.assert_state_equal(H.download(env), st, what="after a %d-step launch" % T)
+    assert np.array_equal(env.reward.cpu().numpy(), ref["reward"]) and np.array_equal(env.done.cpu().numpy(), ref["done"])
+    assert np.array_equal(env.info.cpu().numpy(), ref["info"]) and np.array_equal(env.dmin.cpu().numpy(), ref["dmin"])
+    assert np.array_equal(env.hh_count.cpu().numpy(), ref["hh_count"])
+    np.testing.assert_array_equal(env.human_act.cpu().numpy(), ref["human_act"])
+
+
+def test_rollout_rejects_bad_arguments():
+    torch = _torch()
+    from modelcrowdnav_amd import _hip
+    env = H.make_vec_env(8, 5)
+    env.reset("test", test_cases=list(range(8)))
+    with pytest.raises(ValueError):
+        env.rollout(torch.zeros(3, 7, 2, dtype=torch.float64, device=env.device))
+    with pytest.raises(_hip.McnError):
+        env.rollout(torch.zeros(0, 8, 2, dtype=torch.float64, device=env.device))
+
+
 def test_unicycle_robot_matches_oracle_and_reference(golden_dir):
     """Robot with (v, r) actions (agent.py:110-135, crowd_sim.py:353-355).  cos/sin differ between numpy, libm
     and the device by an ulp, so float state is held to 1e-12; masks stay exact on these inputs."""

@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--humans", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--steps-per-launch", type=int, default=50,
+    ap.add_argument("--steps-per-launch", type=int, default=250,
                     help="env steps handed to one mcn_env_rollout call (the action sequence is known up front); "
                          "1 = one mcn_env_step launch per step")
     ap.add_argument("--sweep", type=str, default="65536,1048576,4194304", help="extra batch sizes for roofline_sweep")

@@ -33,10 +33,33 @@ __device__ __forceinline__ double bperm_d(int byte_addr, double v)
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <int NT, int VIS>
-__global__ __launch_bounds__(64) void env_rollout_quad_kernel(const StepParams p, const int T)
+// SPLIT = true: two wavefronts per workgroup work on the same G envs, as in env_step_quad.hip, but for the whole
+// T-step sequence.  Wavefront 0 owns the humans (ORCA in float32, integration, scenario-pool restarts); wavefront 1
+// owns the robot, the float64 swept-circle / overlap tests, the reward ladder and the Explorer record.  Per step
+// they meet twice through LDS: done flag + restart case (+ robot pose when the robot is visible) one way, the new
+// human positions / velocities / radii the other way.  A lone wavefront issues one instruction every ~5 cycles, so
+// a step costs what its instruction count costs; splitting the step lets the two halves issue side by side and a
+// step then takes max(ORCA, rest) instead of their sum.
+// Pins a wave-uniform value in vector registers.  The kernel argument block is ~110 dwords; left to itself the
+// compiler keeps all of it (plus every lane mask) in the ~100 scalar registers across the step loop and spills the
+// excess to VGPR lanes, paying v_writelane / v_readlane / s_nop on the critical path of every step.  VGPRs are
+// plentiful here (one or two wavefronts per SIMD), so loop-invariant operands live there instead.
+template <class V>
+__device__ __forceinline__ V in_vgpr(V v)
 {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+template <int NT, int VIS, bool UNI, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_quad_kernel(const StepParams p, const int T)
+{
+    __shared__ double2 s_hpos[16], s_hvel[16], s_rpos[16], s_rvel[16];
+    __shared__ double s_hrad[16];
+    __shared__ int s_dn[16], s_case[16];
     if (p.debug_noop) return;
+    const int role = SPLIT ? (int)(threadIdx.x >> 6) : -1;      // 0: humans, 1: robot + ladder + records, -1: both
+    const bool do_orca = role != 1, do_pair = role != 0;
     constexpr int NC = NT - 1 + VIS;          // candidates per human, <= 4
     constexpr int LPE = 4 * NT;               // lanes per env
     constexpr int G = 64 / LPE;               // envs per wavefront
@@ -49,12 +72,17 @@ __global__ __launch_bounds__(64) void env_rollout_quad_kernel(const StepParams p
     const bool active = (g < G) && (e < p.E);
     const long eb = active ? e : 0;
     const long a = eb * NT + h;
+    const int gi = g < G ? g : 0;             // LDS slots of this lane's env / human (idle lanes alias slot 0, read-only)
+    const int hi = g < G ? g * NT + h : 0;
     const mcn_env_cfg &c = p.cfg;
     const mcn_rollout &ro = p.roll;
-    const double dt = c.time_step;
-    const bool lead = active && r == 0;       // owns the per-env records
-    const bool hlead = active && k == 0;      // owns the human's records
-    const bool unicycle = c.robot_kinematics == MCN_KIN_UNICYCLE;
+    const double dt = in_vgpr(c.time_step);
+    const double k_timeout_at = in_vgpr(c.time_limit - 1), k_time_limit = in_vgpr(c.time_limit);
+    const double k_collision = in_vgpr(c.collision_penalty), k_success = in_vgpr(c.success_reward);
+    const double k_discomfort = in_vgpr(c.discomfort_dist), k_factor = in_vgpr(c.discomfort_penalty_factor);
+    const bool lead = active && r == 0 && do_pair;       // owns the per-env records
+    const bool hlead = active && k == 0 && do_orca;      // owns the human's records
+    constexpr bool unicycle = UNI;            // compile-time: the holonomic kernel carries no float64 sin / cos code
     const bool has_state = p.has_roll && ro.state != nullptr;
     const bool do_reset = p.has_roll && ro.pool_hpos != nullptr;
     const bool track = c.track_human_times && p.st.human_times != nullptr;
@@ -72,8 +100,9 @@ __global__ __launch_bounds__(64) void env_rollout_quad_kernel(const StepParams p
     const double rrad = p.st.rrad[eb];
     double gtime = p.st.gtime[eb];
     double rtheta = p.st.rtheta ? p.st.rtheta[eb] : 0.0;
+    // the Explorer record is held (redundantly, like the robot) by every lane of the env: no broadcast per step
     mcn_roll_rec rs = {0, 0, 0, 0, 0, 0};
-    if (lead && has_state) rs = ro.state[e];
+    if (has_state) rs = ro.state[eb];
 
     const bool cand_h = k < NT - 1;                          // candidate is another human
     const bool cand_r = VIS && (k == NT - 1);                // candidate is the robot
@@ -81,125 +110,186 @@ __global__ __launch_bounds__(64) void env_rollout_quad_kernel(const StepParams p
     const int l0 = lane - r;
     const int src = ((l0 + 4 * j) & 63) << 2;                // a lane of the quad that owns human j
 
-    double2 act_next = reinterpret_cast<const double2 *>(p.actions)[eb];
+    // per-lane cursors / wave-uniform operands of the rare paths, all in VGPRs
+    const double2 *act_ptr = reinterpret_cast<const double2 *>(p.actions) + eb;
+    const long act_stride = in_vgpr((long)p.E);
+    const double *disc_table = in_vgpr(ro.disc_table);
+    const int disc_last = in_vgpr(ro.disc_len - 1);
+    const int k_stride = in_vgpr(ro.case_stride), k_pool = in_vgpr(ro.pool_size);
+    double *fin_return = in_vgpr(ro.fin_return), *fin_time = in_vgpr(ro.fin_time);
+    uint8_t *fin_info = in_vgpr(ro.fin_info);
+    const int fin_slots = in_vgpr(ro.fin_slots);
+    const long fin_stride = in_vgpr((long)p.E);
+    const double2 *pool_hpos = in_vgpr(reinterpret_cast<const double2 *>(ro.pool_hpos));
+    const double2 *pool_hgoal = in_vgpr(reinterpret_cast<const double2 *>(ro.pool_hgoal));
+    const double2 *pool_hvel = in_vgpr(reinterpret_cast<const double2 *>(ro.pool_hvel));
+    const double *pool_hrad = in_vgpr(ro.pool_hrad), *pool_hvpref = in_vgpr(ro.pool_hvpref);
+    const double2 k_start = make_double2(in_vgpr(ro.robot_start[0]), in_vgpr(ro.robot_start[1]));
+    const double2 k_goal = make_double2(in_vgpr(ro.robot_goal[0]), in_vgpr(ro.robot_goal[1]));
+    const double k_theta0 = in_vgpr(ro.robot_theta0);
+    const bool has_theta = p.st.rtheta != nullptr;
+    double2 act_next = *act_ptr;
     mcn_step_rec o_last = {0, 0, 0, 0, 0, 0};
     double hax = 0, hay = 0;
 
     for (int t = 0; t < T; ++t) {
         const double2 act = act_next;
-        if (t + 1 < T) act_next = reinterpret_cast<const double2 *>(p.actions)[(long)(t + 1) * p.E + eb];
+        act_ptr += act_stride;
+        if (do_pair && t + 1 < T) act_next = *act_ptr;
         double ep_disc = 0;
-        if (lead && has_state) ep_disc = ro.disc_table[rs.ep_steps < ro.disc_len ? rs.ep_steps : ro.disc_len - 1];
+        if (do_pair && has_state) ep_disc = disc_table[rs.ep_steps < disc_last ? rs.ep_steps : disc_last];
 
         // ---- candidate neighbour: from the quad that owns it instead of from memory ----
         double2 cpos;
         cpos.x = bperm_d(src, pos.x);
         cpos.y = bperm_d(src, pos.y);
-        float cvx = bperm_f(src, (float)vel.x), cvy = bperm_f(src, (float)vel.y);
         double crd = bperm_d(src, rad);
-        if (cand_r) { cpos = rpos; cvx = (float)rvel.x; cvy = (float)rvel.y; crd = rrad; }
+        if (cand_r) { cpos = rpos; crd = rrad; }
+
+        int dn = 0, case_g = 0;
+        double t_new = 0;
 
         // ---- K1: ORCA ----
-        float rx, ry;
-        quad_orca_velocity(c, lane, k, cand_h || cand_r, pos, vel, goal, rad, vpref,
-                           make_float4((float)cpos.x, (float)cpos.y, cvx, cvy), crd, dt, rx, ry);
-        hax = (double)rx; hay = (double)ry;
+        if (do_orca) {
+            float cvx = bperm_f(src, (float)vel.x), cvy = bperm_f(src, (float)vel.y);
+            if (cand_r) { cvx = (float)rvel.x; cvy = (float)rvel.y; }
+            float rx, ry;
+            quad_orca_velocity(c, lane, k, cand_h || cand_r, pos, vel, goal, rad, vpref,
+                               make_float4((float)cpos.x, (float)cpos.y, cvx, cvy), crd, dt, rx, ry);
+            hax = (double)rx; hay = (double)ry;
+        }
 
-        // ---- K2: swept circle per quad, one human-human pair per lane (as env_step_quad.hip) ----
-        double2 eff = act;
-        if (unicycle) {
-            eff.x = act.x * cos(act.y + rtheta);
-            eff.y = act.x * sin(act.y + rtheta);
-        }
-        double cd;
-        {
-            const double px = pos.x - rpos.x, py = pos.y - rpos.y;
-            const double vx = vel.x - eff.x, vy = vel.y - eff.y;
-            cd = p2s_origin(px, py, px + vx * dt, py + vy * dt) - rad - rrad;
-        }
-        int hh;
-        {
-            const double dx = pos.x - cpos.x, dy = pos.y - cpos.y;
-            const bool counted = c.count_hh && cand_h && j > h;
-            hh = (counted && (sqrt(dx * dx + dy * dy) - rad - crd) < 0) ? 1 : 0;
-        }
-        hh += __builtin_amdgcn_update_dpp(0, hh, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
-        hh += __builtin_amdgcn_update_dpp(0, hh, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
-        double dmin = INFINITY;
-        int hh_sum = 0;
+        if (do_pair) {
+            // ---- K2: swept circle per quad, one human-human pair per lane (as env_step_quad.hip) ----
+            double2 eff = act;
+            if (unicycle) {
+                eff.x = act.x * cos(act.y + rtheta);
+                eff.y = act.x * sin(act.y + rtheta);
+            }
+            double cd;
+            {
+                const double px = pos.x - rpos.x, py = pos.y - rpos.y;
+                const double vx = vel.x - eff.x, vy = vel.y - eff.y;
+                cd = p2s_origin(px, py, px + vx * dt, py + vy * dt) - rad - rrad;
+            }
+            int hh;
+            {
+                const double dx = pos.x - cpos.x, dy = pos.y - cpos.y;
+                const bool counted = (c.count_hh != 0) & cand_h & (j > h);
+                hh = (counted & ((sqrt(dx * dx + dy * dy) - rad - crd) < 0)) ? 1 : 0;
+            }
+            hh += __builtin_amdgcn_update_dpp(0, hh, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+            hh += __builtin_amdgcn_update_dpp(0, hh, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+            double dmin = INFINITY;
+            int hh_sum = 0;
 #pragma unroll
-        for (int q = 0; q < NT; ++q) {
-            const int s = (l0 + 4 * q) & 63;
-            dmin = fmin(dmin, __shfl(cd, s));
-            hh_sum += __shfl(hh, s);
-        }
+            for (int q = 0; q < NT; ++q) {
+                const int s = (l0 + 4 * q) & 63;
+                dmin = fmin(dmin, __shfl(cd, s));
+                hh_sum += __shfl(hh, s);
+            }
 
-        // ---- K3: ladder, on every lane of the env ----
-        double endx, endy, new_theta = rtheta, nrvx, nrvy;
-        if (unicycle) {
-            const double th = rtheta + act.y;
-            endx = rpos.x + cos(th) * act.x * dt;
-            endy = rpos.y + sin(th) * act.x * dt;
-            new_theta = pymod(rtheta + act.y, 2 * M_PI);
-            nrvx = act.x * cos(new_theta); nrvy = act.x * sin(new_theta);
-        } else {
-            endx = rpos.x + act.x * dt; endy = rpos.y + act.y * dt;
-            nrvx = act.x; nrvy = act.y;
-        }
-        const bool reaching = norm2(endx - rgoal.x, endy - rgoal.y) < rrad;
-        double rew; int dn, inf;
-        if (gtime >= c.time_limit - 1)      { rew = 0; dn = 1; inf = MCN_INFO_TIMEOUT; }
-        else if (dmin < 0)                  { rew = c.collision_penalty; dn = 1; inf = MCN_INFO_COLLISION; }
-        else if (reaching)                  { rew = c.success_reward; dn = 1; inf = MCN_INFO_REACHGOAL; }
-        else if (dmin < c.discomfort_dist)  { rew = (dmin - c.discomfort_dist) * c.discomfort_penalty_factor * dt; dn = 0; inf = MCN_INFO_DANGER; }
-        else                                { rew = 0; dn = 0; inf = MCN_INFO_NOTHING; }
-        o_last.reward = rew; o_last.dmin = dmin; o_last.done = (uint8_t)dn; o_last.info = (uint8_t)inf;
-        o_last.hh_count = hh_sum;
-        const double t_new = gtime + dt;
-
-        // ---- Explorer accounting on the env's lead lane (explorer.py:88-99,124) ----
-        const int case_g = __shfl(rs.next_case, l0 & 63);
-        if (lead && has_state) {
-            if (inf == MCN_INFO_DANGER) { rs.danger_count += 1; rs.danger_dist_sum += dmin; }
-            const double ret = rs.ep_return + ep_disc * rew;
-            if (dn) {
-                const int kf = rs.fin_count;
-                const bool keep = (ro.fin_slots == 1) || (kf < ro.fin_slots);
-                const long rec = (long)(ro.fin_slots == 1 ? 0 : kf) * p.E + e;
-                if (keep && ro.fin_return) ro.fin_return[rec] = ret;
-                if (keep && ro.fin_time)   ro.fin_time[rec] = (inf == MCN_INFO_TIMEOUT) ? c.time_limit : t_new;
-                if (keep && ro.fin_info)   ro.fin_info[rec] = (uint8_t)inf;
-                rs.fin_count = kf + 1; rs.ep_return = 0; rs.ep_steps = 0;
-                if (do_reset) rs.next_case = (rs.next_case + ro.case_stride) % ro.pool_size;
+            // ---- K3: ladder, on every lane of the env ----
+            double endx, endy, new_theta = rtheta, nrvx, nrvy;
+            if (unicycle) {
+                const double th = rtheta + act.y;
+                endx = rpos.x + cos(th) * act.x * dt;
+                endy = rpos.y + sin(th) * act.x * dt;
+                new_theta = pymod(rtheta + act.y, 2 * M_PI);
+                nrvx = act.x * cos(new_theta); nrvy = act.x * sin(new_theta);
             } else {
-                rs.ep_return = ret; rs.ep_steps += 1;
+                endx = rpos.x + act.x * dt; endy = rpos.y + act.y * dt;
+                nrvx = act.x; nrvy = act.y;
+            }
+            const bool reaching = norm2(endx - rgoal.x, endy - rgoal.y) < rrad;
+            double rew; int inf;
+            if (gtime >= k_timeout_at)          { rew = 0; dn = 1; inf = MCN_INFO_TIMEOUT; }
+            else if (dmin < 0)                  { rew = k_collision; dn = 1; inf = MCN_INFO_COLLISION; }
+            else if (reaching)                  { rew = k_success; dn = 1; inf = MCN_INFO_REACHGOAL; }
+            else if (dmin < k_discomfort)       { rew = (dmin - k_discomfort) * k_factor * dt; dn = 0; inf = MCN_INFO_DANGER; }
+            else                                { rew = 0; dn = 0; inf = MCN_INFO_NOTHING; }
+            o_last.reward = rew; o_last.dmin = dmin; o_last.done = (uint8_t)dn; o_last.info = (uint8_t)inf;
+            o_last.hh_count = hh_sum;
+            t_new = gtime + dt;
+
+            // ---- Explorer accounting (explorer.py:88-99,124): every lane of the env updates its copy of the
+            //      record with selects; only the finished-episode stores are the lead lane's ----
+            case_g = rs.next_case;
+            if (has_state) {
+                const bool danger = inf == MCN_INFO_DANGER;
+                rs.danger_count += danger ? 1 : 0;
+                rs.danger_dist_sum = danger ? rs.danger_dist_sum + dmin : rs.danger_dist_sum;
+                const double ret = rs.ep_return + ep_disc * rew;
+                if (lead && dn) {
+                    const int kf = rs.fin_count;
+                    const bool keep = (fin_slots == 1) || (kf < fin_slots);
+                    const long rec = (long)(fin_slots == 1 ? 0 : kf) * fin_stride + e;
+                    if (keep && fin_return) fin_return[rec] = ret;
+                    if (keep && fin_time)   fin_time[rec] = (inf == MCN_INFO_TIMEOUT) ? k_time_limit : t_new;
+                    if (keep && fin_info)   fin_info[rec] = (uint8_t)inf;
+                }
+                rs.fin_count += dn;
+                rs.ep_return = dn ? 0.0 : ret;
+                rs.ep_steps = dn ? 0 : rs.ep_steps + 1;
+                if (do_reset) {
+                    const int nc = (rs.next_case + k_stride) % k_pool;
+                    rs.next_case = dn ? nc : rs.next_case;
+                }
+            }
+
+            // ---- robot: integrate, or back to the start pose ----
+            if (do_reset && dn) {
+                rpos = k_start;
+                rgoal = k_goal;
+                rvel = make_double2(0, 0);
+                if (has_theta) rtheta = k_theta0;
+                gtime = 0;
+            } else {
+                rpos = make_double2(endx, endy);
+                rvel = make_double2(nrvx, nrvy);
+                if (unicycle) rtheta = new_theta;
+                gtime = t_new;
             }
         }
 
-        // ---- integrate, or restart from the scenario pool ----
-        if (do_reset && dn) {
-            if (active) {
-                const long pa = (long)case_g * NT + h;
-                pos = reinterpret_cast<const double2 *>(ro.pool_hpos)[pa];
-                goal = reinterpret_cast<const double2 *>(ro.pool_hgoal)[pa];
-                rad = ro.pool_hrad[pa];
-                vpref = ro.pool_hvpref[pa];
-                vel = ro.pool_hvel ? reinterpret_cast<const double2 *>(ro.pool_hvel)[pa] : make_double2(0, 0);
+        if (SPLIT) {
+            // hand-off 1: wavefront 1 publishes the done flag, the restart case, the clock (and the robot's new pose)
+            if (lead) {
+                s_dn[gi] = dn; s_case[gi] = case_g;
+                if (VIS) { s_rpos[gi] = rpos; s_rvel[gi] = rvel; }
             }
-            htime = 0;
-            rpos = make_double2(ro.robot_start[0], ro.robot_start[1]);
-            rgoal = make_double2(ro.robot_goal[0], ro.robot_goal[1]);
-            rvel = make_double2(0, 0);
-            if (p.st.rtheta) rtheta = ro.robot_theta0;
-            gtime = 0;
-        } else {
-            pos = make_double2(pos.x + hax * dt, pos.y + hay * dt);
-            vel = make_double2(hax, hay);
-            if (track && htime == 0 && norm2(pos.x - goal.x, pos.y - goal.y) < rad) htime = t_new;   // agent.py:137-138
-            rpos = make_double2(endx, endy);
-            rvel = make_double2(nrvx, nrvy);
-            if (unicycle) rtheta = new_theta;
-            gtime = t_new;
+            __syncthreads();
+            if (role == 0) {
+                dn = s_dn[gi]; case_g = s_case[gi];
+                if (VIS) { rpos = s_rpos[gi]; rvel = s_rvel[gi]; }
+            }
+        }
+
+        // ---- humans: integrate, or restart from the scenario pool ----
+        if (do_orca) {
+            if (do_reset && dn) {
+                if (active) {
+                    const long pa = (long)case_g * NT + h;
+                    pos = pool_hpos[pa];
+                    goal = pool_hgoal[pa];
+                    rad = pool_hrad[pa];
+                    vpref = pool_hvpref[pa];
+                    vel = pool_hvel ? pool_hvel[pa] : make_double2(0, 0);
+                }
+                htime = 0;
+            } else {
+                pos = make_double2(pos.x + hax * dt, pos.y + hay * dt);
+                vel = make_double2(hax, hay);
+                // agent.py:137-138; the clock of the step just taken (wavefront 0 keeps its own copy of it)
+                if (track && htime == 0 && norm2(pos.x - goal.x, pos.y - goal.y) < rad) htime = SPLIT ? gtime + dt : t_new;
+            }
+        }
+        if (SPLIT) {
+            if (role == 0) gtime = (do_reset && dn) ? 0.0 : gtime + dt;
+            // hand-off 2: wavefront 0 publishes the humans' new state
+            if (hlead) { s_hpos[hi] = pos; s_hvel[hi] = vel; s_hrad[hi] = rad; }
+            __syncthreads();
+            if (role == 1) { pos = s_hpos[hi]; vel = s_hvel[hi]; rad = s_hrad[hi]; }
         }
     }
 
@@ -226,12 +316,24 @@ __global__ __launch_bounds__(64) void env_rollout_quad_kernel(const StepParams p
     }
 }
 
+template <int NT, int VIS, bool UNI>
+static void launch_rollout_kin(const StepParams &p, int T, int blocks, hipStream_t stream)
+{
+    if (p.quad_split)
+        hipLaunchKernelGGL((env_rollout_quad_kernel<NT, VIS, UNI, true>), dim3(blocks), dim3(128), 0, stream, p, T);
+    else
+        hipLaunchKernelGGL((env_rollout_quad_kernel<NT, VIS, UNI, false>), dim3(blocks), dim3(64), 0, stream, p, T);
+}
+
 template <int NT, int VIS>
 static void launch_rollout_one(const StepParams &p, int T, hipStream_t stream)
 {
     constexpr int G = 64 / (4 * NT);
     const int blocks = (p.E + G - 1) / G;
-    hipLaunchKernelGGL((env_rollout_quad_kernel<NT, VIS>), dim3(blocks), dim3(64), 0, stream, p, T);
+    if (p.cfg.robot_kinematics == MCN_KIN_UNICYCLE)
+        launch_rollout_kin<NT, VIS, true>(p, T, blocks, stream);
+    else
+        launch_rollout_kin<NT, VIS, false>(p, T, blocks, stream);
 }
 
 // Returns true when the fused T-step kernel handles this problem (ORCA humans, <= 4 neighbours each, update).

@@ -98,6 +98,13 @@ int mcn_env_rollout(const mcn_env_cfg *cfg, const mcn_env_state *st, const doubl
     // MCN_ROLLOUT_FUSED=0/1 overrides (tests, tuning).
     const char *env_fused = getenv("MCN_ROLLOUT_FUSED");
     const bool fused = env_fused ? atoi(env_fused) != 0 : p.quad_max_envs >= E;
+    {
+        // two cooperating wavefronts per env group while the doubled grid still finds idle issue slots
+        const char *env_split = getenv("MCN_ROLLOUT_SPLIT");
+        const int envs_per_wave = 64 / (4 * N) > 0 ? 64 / (4 * N) : 1;
+        const long waves = ((long)E + envs_per_wave - 1) / envs_per_wave;
+        p.quad_split = env_split ? atoi(env_split) : (waves <= 1400 ? 1 : 0);
+    }
     if (fused && !p.force_generic && mcn::launch_env_rollout_quad(p, T, (hipStream_t)stream))
         return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
     for (int32_t t = 0; t < T; ++t) {

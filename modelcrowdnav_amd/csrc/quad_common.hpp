@@ -39,21 +39,21 @@ __device__ __forceinline__ bool lp1_rt(const float4 (&L)[4], int no, float radiu
     const float sq = sqrtf(disc);
     float tl = -dp - sq;
     float tr = -dp + sq;
+    // straight-line: every lane runs all three steps and masks them with selects (a lone wavefront per SIMD pays
+    // for every exec-mask instruction; the quotient of a skipped / parallel line is computed and discarded)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        if (i < no) {
-            const float4 li = L[i];
-            const float den = det2(ln.z, ln.w, li.z, li.w);
-            const float num = det2(li.z, li.w, ln.x - li.x, ln.y - li.y);
-            if (fabsf(den) <= kRvoEps) {
-                if (num < 0.0f) ok = false;
-            } else {
-                const float t = num / den;
-                if (den >= 0.0f) tr = fminf(tr, t);
-                else             tl = fmaxf(tl, t);
-                if (tl > tr) ok = false;
-            }
-        }
+        const float4 li = L[i];
+        const float den = det2(ln.z, ln.w, li.z, li.w);
+        const float num = det2(li.z, li.w, ln.x - li.x, ln.y - li.y);
+        const float t = num / den;
+        const bool live = i < no;
+        const bool par = fabsf(den) <= kRvoEps;
+        const bool cut = live & !par;
+        const float ntr = fminf(tr, t), ntl = fmaxf(tl, t);
+        tr = (cut & (den >= 0.0f)) ? ntr : tr;
+        tl = (cut & !(den >= 0.0f)) ? ntl : tl;
+        ok = ok & !(live & par & (num < 0.0f)) & !(cut & (tl > tr));
     }
     float t;
     if (DIR) {
@@ -101,6 +101,42 @@ __device__ __forceinline__ bool lp3_candidate(const float4 (&L)[4], int no, floa
     return fail == m;
 }
 
+// orca_line_merged (orca_static.hpp) as one straight-line block: the cut-off-circle and the leg projections are both
+// evaluated and the result selected.  Same operations on the selected side, so the same bits.
+__device__ __forceinline__ float4 orca_line_select(float px, float py, float vx, float vy, float radius, float4 o,
+                                                   float orad, float inv_th, float inv_ts)
+{
+    const float rpx = o.x - px, rpy = o.y - py;
+    const float rvx = vx - o.z, rvy = vy - o.w;
+    const float dist_sq = dot2(rpx, rpy, rpx, rpy);
+    const float cr = radius + orad;
+    const float cr_sq = cr * cr;
+    const bool apart = dist_sq > cr_sq;
+    const float inv = apart ? inv_th : inv_ts;          // collision case uses 1/timeStep
+    const float wx = rvx - inv * rpx, wy = rvy - inv * rpy;
+    const float wl_sq = dot2(wx, wy, wx, wy);
+    const float dp1 = dot2(wx, wy, rpx, rpy);
+    const bool circle = !apart | ((dp1 < 0.0f) & (dp1 * dp1 > cr_sq * wl_sq));
+    // cut-off circle
+    const float wl = sqrtf(wl_sq);
+    const float iw = 1.0f / wl;
+    const float uwx = wx * iw, uwy = wy * iw;
+    const float sc = cr * inv - wl;
+    const float cux = sc * uwx, cuy = sc * uwy;
+    // legs
+    const float leg = sqrtf(dist_sq - cr_sq);
+    const float id = 1.0f / dist_sq;
+    const bool left = det2(rpx, rpy, wx, wy) > 0.0f;
+    const float lx = (rpx * leg - rpy * cr) * id, ly = (rpx * cr + rpy * leg) * id;
+    const float rx = -((rpx * leg + rpy * cr) * id), ry = -((-rpx * cr + rpy * leg) * id);
+    const float gx = left ? lx : rx, gy = left ? ly : ry;
+    const float dp2 = dot2(rvx, rvy, gx, gy);
+    const float lux = dp2 * gx - rvx, luy = dp2 * gy - rvy;
+    const float dx = circle ? uwy : gx, dy = circle ? -uwx : gy;
+    const float ux = circle ? cux : lux, uy = circle ? cuy : luy;
+    return make_float4(vx + 0.5f * ux, vy + 0.5f * uy, dx, dy);
+}
+
 // ORCA velocity of the human owning this quad.  Lane k holds candidate neighbour k: `o` = its (px, py, vx, vy) in
 // float32, `crd` its radius, `cand_valid` whether the slot is populated.  The result is identical on the four
 // lanes of the quad (layout: lane = 4 * human + k).
@@ -120,17 +156,16 @@ __device__ __forceinline__ void quad_orca_velocity(const mcn_env_cfg &c, int lan
     const float d0 = qbf<0>(d), d1 = qbf<1>(d), d2 = qbf<2>(d), d3 = qbf<3>(d);
     const int i0 = qbi<0>(in), i1 = qbi<1>(in), i2 = qbi<2>(in), i3 = qbi<3>(in);
     const int nin = i0 + i1 + i2 + i3;
-    int rank;
-    if (in) {        // stable ascending order among the in-range candidates (RVO2 insertAgentNeighbor)
-        rank = (i0 && (d0 < d || (d0 == d && 0 < k))) + (i1 && (d1 < d || (d1 == d && 1 < k))) +
-               (i2 && (d2 < d || (d2 == d && 2 < k))) + (i3 && (d3 < d || (d3 == d && 3 < k)));
-    } else {         // the rest fill the remaining slots in lane order so that ranks stay a permutation
-        rank = nin + ((0 < k && !i0) ? 1 : 0) + ((1 < k && !i1) ? 1 : 0) + ((2 < k && !i2) ? 1 : 0);
-    }
+    // stable ascending order among the in-range candidates (RVO2 insertAgentNeighbor); the rest fill the
+    // remaining slots in lane order so that ranks stay a permutation
+    const int rank_in = ((i0 != 0) & ((d0 < d) | ((d0 == d) & (0 < k)))) + ((i1 != 0) & ((d1 < d) | ((d1 == d) & (1 < k)))) +
+                        ((i2 != 0) & ((d2 < d) | ((d2 == d) & (2 < k)))) + ((i3 != 0) & ((d3 < d) | ((d3 == d) & (3 < k))));
+    const int rank_out = nin + (((0 < k) & !i0) ? 1 : 0) + (((1 < k) & !i1) ? 1 : 0) + (((2 < k) & !i2) ? 1 : 0);
+    const int rank = in ? rank_in : rank_out;
     int nl = nin < c.orca_max_neighbors ? nin : c.orca_max_neighbors;
     const float inv_th = 1.0f / c.orca_time_horizon;
     const float inv_ts = 1.0f / (float)dt;
-    const float4 mine = orca_line_merged(fpx, fpy, fvx, fvy, frad, o, orad, inv_th, inv_ts);
+    const float4 mine = orca_line_select(fpx, fpy, fvx, fvy, frad, o, orad, inv_th, inv_ts);
     // route my half-plane to lane `rank` of the quad, then share all four
     const int dst = ((lane & ~3) | rank) << 2;
     float4 srt;
@@ -143,26 +178,30 @@ __device__ __forceinline__ void quad_orca_velocity(const mcn_env_cfg &c, int lan
     // speculative 1-D LPs, one per lane; then the incremental LP is four compare-and-take steps
     float cx, cy;
     const int okm = lp1_rt<false>(L, k, ms, prefx, prefy, cx, cy) ? 1 : 0;
-    if (dot2(prefx, prefy, prefx, prefy) > ms * ms) {
-        const float inv = 1.0f / sqrtf(dot2(prefx, prefy, prefx, prefy));
-        rx = ms * (prefx * inv); ry = ms * (prefy * inv);
-    } else {
-        rx = prefx; ry = prefy;
+    {
+        const float pp = dot2(prefx, prefy, prefx, prefy);
+        const float inv = 1.0f / sqrtf(pp);
+        const bool clip = pp > ms * ms;
+        rx = clip ? ms * (prefx * inv) : prefx;
+        ry = clip ? ms * (prefy * inv) : prefy;
     }
     int fail = nl;
 #define MCN_LP2_TAKE(I)                                                                        \
     {                                                                                          \
         const int ok_i = qbi<I>(okm); const float cx_i = qbf<I>(cx), cy_i = qbf<I>(cy);        \
-        if (I < nl && fail == nl && det2(L[I].z, L[I].w, L[I].x - rx, L[I].y - ry) > 0.0f) {   \
-            if (ok_i) { rx = cx_i; ry = cy_i; } else fail = I;                                  \
-        }                                                                                      \
+        const bool viol = (I < nl) & (fail == nl) & (det2(L[I].z, L[I].w, L[I].x - rx, L[I].y - ry) > 0.0f); \
+        rx = (viol & (ok_i != 0)) ? cx_i : rx; ry = (viol & (ok_i != 0)) ? cy_i : ry;           \
+        fail = (viol & (ok_i == 0)) ? I : fail;                                                 \
     }
     MCN_LP2_TAKE(0) MCN_LP2_TAKE(1) MCN_LP2_TAKE(2) MCN_LP2_TAKE(3)
 #undef MCN_LP2_TAKE
-    if (__any(fail < nl)) {
-        // dense crowd: 3-D LP.  Candidates of all four lines in parallel, combined in line order.
-        float c3x, c3y;
-        const int ok3 = lp3_candidate(L, k, ms, c3x, c3y) ? 1 : 0;
+    if (fail < nl) {
+        // dense crowd: 3-D LP.  Candidates of the lines from `fail` on, in parallel, combined in line order.  The
+        // region is entered per quad (fail / nl are quad-uniform, so the quad broadcasts below see all four
+        // lanes); with only the few lanes that need a candidate active, most inner 1-D LPs are skipped outright.
+        float c3x = 0.0f, c3y = 0.0f;
+        int ok3 = 0;
+        if (k >= fail && k < nl) ok3 = lp3_candidate(L, k, ms, c3x, c3y) ? 1 : 0;
         float dist = 0.0f;
 #define MCN_LP3_TAKE(I)                                                                        \
     {                                                                                          \

@@ -197,7 +197,8 @@ def _snapshot(env):
 
 @pytest.mark.parametrize("N,visible", [(5, False), (4, True), (3, False), (1, True), (2, False)])
 @pytest.mark.parametrize("with_pool", [True, False])
-def test_rollout_launch_equals_single_steps(N, visible, with_pool, monkeypatch):
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_rollout_launch_equals_single_steps(N, visible, with_pool, split, monkeypatch):
     """mcn_env_rollout (T steps in one launch, state in registers) == T mcn_env_step calls, every byte of state,
     step record, Explorer accounting and finished-episode records; episodes end and restart inside the sequence."""
     torch = _torch()
@@ -206,6 +207,7 @@ def test_rollout_launch_equals_single_steps(N, visible, with_pool, monkeypatch):
     sp, aa = rng.uniform(0, 1, (T, E)), rng.uniform(0, 2 * np.pi, (T, E))
     acts = torch.from_numpy(np.stack([sp * np.cos(aa), sp * np.sin(aa)], -1))
     monkeypatch.setenv("MCN_ROLLOUT_FUSED", "1")
+    monkeypatch.setenv("MCN_ROLLOUT_SPLIT", split)     # one wavefront per env group / two cooperating ones
     a = _rollout_env(E, N, visible, with_pool, fin_slots=2)
     b = _rollout_env(E, N, visible, with_pool, fin_slots=2)
     acts_d = acts.to(a.device)

@@ -23,7 +23,11 @@ def main():
     ap.add_argument("--visible", action="store_true")
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--sarl", action="store_true")
+    ap.add_argument("--rollout", type=int, default=0, help="time mcn_env_rollout with this many steps per launch")
     a = ap.parse_args()
+    if a.rollout:
+        rollout_bench(a)
+        return
     if a.sarl:
         for N in [int(x) for x in str(a.humans).split(",")]:
             sarl_bench(4096, N)
@@ -57,6 +61,26 @@ def main():
         del env
 
 
+
+
+def rollout_bench(a):
+    """Per-step time of the fused T-step launch (MCN_ROLLOUT_FUSED=1 forces it at any batch size)."""
+    dev = torch.device("cuda", 0)
+    N, T = a.humans, a.rollout
+    os.environ["MCN_ROLLOUT_FUSED"] = "1"
+    for E in [int(x) for x in a.sizes.split(",")]:
+        env, _ = bench.build_env(E, N, 0, dev)
+        env.robot.visible = a.visible
+        acts = bench.make_actions(T, E, E, 0, dev)
+        env.rollout(acts)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e9
+        for rep in range(5):
+            s.record(); env.rollout(acts); e.record(); torch.cuda.synchronize()
+            best = min(best, s.elapsed_time(e) / T)
+        print("N=%d E=%8d rollout T=%d  %9.3f us/step  %8.1f M env-steps/s" % (N, E, T, best * 1e3, E / best / 1e3))
+        del env
 
 
 def sarl_bench(E=4096, N=5, iters=5):

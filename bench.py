@@ -129,10 +129,12 @@ def pmc_traffic(E, given, steps_per_launch=1):
     passes, gfx950 FETCH_SIZE x2 correction; profiles/r01_pmc_env_step.json).  None where no such run exists."""
     global _PMC
     if _PMC is None:
-        try:
-            _PMC = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_env_step.json")))["kernels"]
-        except Exception:
-            _PMC = []
+        _PMC = []
+        for name in ("r01_pmc_env_step.json", "r01_pmc_env_rollout.json"):
+            try:
+                _PMC += json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+            except Exception:
+                pass
     for k in _PMC:
         if k["envs"] == E and ("pairwise-only" in k["what"]) == bool(given) and k.get("steps_per_launch", 1) == steps_per_launch:
             return k["traffic_bytes_per_launch"]

@@ -76,11 +76,13 @@ class VecExplorer(object):
 
     def run_k_episodes(self, k, phase, update_memory=False, imitation_learning=False, episode=None,
                        print_failure=False, returnRate=True, returnNav=False, action_fn=None, max_steps=None,
-                       total_envs=None):
+                       total_envs=None, action_seq=None):
         """Returns what Explorer.run_k_episodes returns (explorer.py:146-151):
         (avg cumulative reward, success rate, collision rate, timeout rate[, avg nav time])
         or counts instead of rates when returnRate is False.  `action_fn(env, t) -> [E,2]` overrides the
-        policy (e.g. a random-action baseline)."""
+        policy (e.g. a random-action baseline).  `action_seq` ([T,E,2] device tensor) is a robot whose actions do
+        not depend on the observation: its steps go to the device 32 at a time through mcn_env_rollout (one launch,
+        state in registers) instead of one launch per step; not combinable with update_memory."""
         env = self.env
         rank, ws = mdist.world()
         E_local = env.num_envs
@@ -116,6 +118,17 @@ class VecExplorer(object):
         transformer = (self.target_policy if imitation_learning else self.policy) if update_memory else None
         rec_s, rec_r, rec_d, rec_i = [], [], [], []
         t = 0
+        if action_seq is not None:
+            if update_memory:
+                raise ValueError("action_seq rollouts record no per-step states; use action_fn with update_memory")
+            limit = min(limit, int(action_seq.shape[0]))
+            while t < limit:
+                n = min(32, limit - t)
+                env.rollout(action_seq[t:t + n])
+                t += n
+                if int(bufs["fin_count"].min().item()) >= rounds:
+                    break
+            limit = t                                            # skip the per-step loop below
         while t < limit:
             if update_memory:
                 rec_s.append(transformer.transform_batch(env))           # the state the action is chosen in

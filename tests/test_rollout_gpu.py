@@ -58,6 +58,30 @@ def test_vec_explorer_equals_sequential_loop():
     assert env.case_counter["test"] == k % 500
 
 
+def test_vec_explorer_action_sequence_uses_fused_rollout():
+    """A pre-drawn action sequence run through mcn_env_rollout chunks gives the records of the per-step loop."""
+    import torch
+    from modelcrowdnav_amd.rollout import VecExplorer
+    E, N, k, T = 48, 5, 100, 330
+    rng = np.random.RandomState(5)
+    sp, aa = rng.uniform(0, 1, (T, E)), rng.uniform(0, 2 * np.pi, (T, E))
+    recs = []
+    for fused in (True, False):
+        env = H.make_vec_env(E, N)
+        env.track_human_times = False; env.export_human_actions = False
+        seq = torch.from_numpy(np.stack([sp * np.cos(aa), sp * np.sin(aa)], -1)).to(env.device)
+        ex = VecExplorer(env, env.robot, gamma=0.9, policy=object())
+        if fused:
+            out = ex.run_k_episodes(k, "val", action_seq=seq)
+        else:
+            out = ex.run_k_episodes(k, "val", action_fn=lambda env_, t: seq[t])
+        recs.append((out, ex.last_records))
+    assert recs[0][0] == recs[1][0]
+    for key in ("returns", "infos", "times"):
+        assert recs[0][1][key] == recs[1][1][key], key
+    assert len(set(recs[0][1]["infos"])) > 1
+
+
 def test_crowdsim_e1_with_orca_robot_matches_oracle():
     """BASELINE config 1 plumbing: CrowdSim gym surface, ORCA humans, ORCA robot (test.py --policy orca)."""
     import torch

@@ -242,38 +242,47 @@ def extra_configs(device):
 
 
 def cpu_baseline(N, seconds):
-    """The C oracle's env step (oracle/mcn_oracle.c), one thread, on a bounded sample of the same
-    workload: 4096 envs x 5 humans from the same scenarios, random table actions."""
-    from oracle import cport
+    """The C oracle's env step (oracle/mcn_oracle.c) on a bounded sample of the same workload: 4096 envs x 5
+    humans from the same scenarios, random table actions.  `value` is ONE thread (the reference is single-threaded);
+    `all_cores` runs independent replicas of it as child processes (numpy + ctypes only, they never touch the GPU) on
+    the host cores this process may use, started together."""
+    import subprocess
+    import tempfile
+    from oracle import cport, cpu_replica
     from modelcrowdnav_amd.envs import scenarios as S
+    cport.lib()                                             # build / load once
     E = 4096
-    spec = S.ScenarioSpec()
-    pool = S.scenario_pool(spec, "test", range(500), N, "circle_crossing")
-    sc = pool[np.arange(E) % 500]
-    st = cport.EnvState(E, N)
-    st.hpx[:], st.hpy[:], st.hgx[:], st.hgy[:] = sc[..., 0], sc[..., 1], sc[..., 2], sc[..., 3]
-    st.hr[:], st.hvpref[:] = sc[..., 7], sc[..., 8]
-    st.rpy[:], st.rgy[:], st.rr[:] = -4.0, 4.0, 0.3
-    fresh = st.copy()
-    cfg = cport.default_cfg()
-    tab = action_table().numpy()
-    rng = np.random.RandomState(0)
-    cport.env_step(cfg, st, np.zeros(E), np.zeros(E))      # warm
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        a = tab[rng.randint(0, 81, E)]
-        out = cport.env_step(cfg, st, np.ascontiguousarray(a[:, 0]), np.ascontiguousarray(a[:, 1]))
-        d = out["done"].astype(bool)
-        if d.any():        # auto-reset like the GPU run
-            for k in cport.EnvState.FIELDS_H + cport.EnvState.FIELDS_R + ("gtime", "human_times"):
-                getattr(st, k)[d] = getattr(fresh, k)[d]
-        steps += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or steps >= 20000:
-            break
-    return {"value": round(E * steps / el, 1), "unit": "env-steps/sec", "cores": 1, "kind": "port",
+    pool = S.scenario_pool(S.ScenarioSpec(), "test", range(500), N, "circle_crossing")
+    sc, tab = pool[np.arange(E) % 500], action_table().numpy()
+    n_env_steps, el, steps = cpu_replica.run(cpu_replica.setup(sc, tab, 0), seconds)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 16))                          # the GPU box gives one GPU's share of the host: 16 cores
+    all_cores = None
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "workload.npz")
+        np.savez(path, sc=sc, tab=tab)
+        start_at = time.time() + 4.0
+        secs = max(2.0, seconds / 3)
+        procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_replica", path, str(secs), str(i + 1), str(start_at)],
+                                  cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                 for i in range(cores)]
+        outs = []
+        for pr in procs:
+            try:
+                o, _ = pr.communicate(timeout=secs + 60)
+                outs.append([float(x) for x in o.split()])
+            except Exception:
+                pr.kill()
+        good = [o for o in outs if len(o) == 3]
+        if good:
+            # replicas start together and run for the same duration: the aggregate is the sum of their rates
+            all_cores = {"value": round(sum(o[0] / o[1] for o in good), 1), "unit": "env-steps/sec", "cores": len(good),
+                         "sample": "%d independent replica processes of the same workload, %.1f s each, started "
+                                   "together" % (len(good), secs)}
+    return {"value": round(n_env_steps / el, 1), "unit": "env-steps/sec", "cores": 1, "kind": "port",
             "sample": "%d envs x %d humans x %d steps (%.1f s), C oracle, 1 thread of %d host cores" % (
-                E, N, steps, el, os.cpu_count())}
+                E, N, steps, el, os.cpu_count()),
+            "all_cores": all_cores}
 
 
 def main():

@@ -24,6 +24,38 @@ def average(xs):
     return sum(xs) / len(xs) if xs else 0
 
 
+def value_targets(states, rewards, dones, infos, imitation_learning, gamma_bar, target_model=None, device=None):
+    """explorer.py:153-186 (= datagen.py:520-543) for a whole batched rollout.  states [T,E,N,13] f32, rewards
+    [T,E] f64, dones [T,E] bool, infos [T,E] u8, gamma_bar = gamma ** (time_step * v_pref).  Returns
+    (states [M,N,13], values [M]) of the steps that belong to episodes ending in ReachGoal or Collision (only
+    those feed the memory, explorer.py:107-110 / datagen.py:482-484)."""
+    T, E = rewards.shape
+    gbar = gamma_bar
+    keep = torch.zeros(T, E, dtype=torch.bool, device=rewards.device)
+    values = torch.zeros(T, E, dtype=torch.float64, device=rewards.device)
+    good_end = (infos == _hip.INFO_REACHGOAL) | (infos == _hip.INFO_COLLISION)
+    if not imitation_learning:
+        with torch.no_grad():
+            nxt = target_model(states[1:].reshape(-1, states.shape[2], states.shape[3]).to(device or states.device))
+        nxt = torch.cat([nxt.view(T - 1, E).double(), torch.zeros(1, E, dtype=torch.float64, device=nxt.device)], 0)
+    ep_ok = torch.zeros(E, dtype=torch.bool, device=rewards.device)      # episode containing step t ends well
+    run = torch.zeros(E, dtype=torch.float64, device=rewards.device)     # discounted tail sum (IL)
+    for t in range(T - 1, -1, -1):
+        d = dones[t]
+        ep_ok = torch.where(d, good_end[t], ep_ok)          # a done at t starts (going backwards) a new episode
+        if imitation_learning:
+            run = torch.where(d, rewards[t], rewards[t] + gbar * run)
+            values[t] = run
+        else:
+            values[t] = torch.where(d, rewards[t], rewards[t] + gbar * nxt[t])
+        keep[t] = ep_ok
+    # steps after the last done of an env belong to an unfinished episode: ep_ok is False there by construction
+    idx = keep.t().reshape(-1).nonzero().squeeze(1)           # (env, time) order
+    flat_states = states.permute(1, 0, 2, 3).reshape(T * E, states.shape[2], states.shape[3])
+    flat_values = values.t().reshape(-1)
+    return flat_states[idx], flat_values[idx].float()
+
+
 class VecExplorer(object):
     def __init__(self, env, robot, device=None, gamma=0.9, policy=None, memory=None, target_policy=None):
         self.env, self.robot, self.gamma = env, robot, gamma
@@ -38,35 +70,8 @@ class VecExplorer(object):
         self.target_model = copy.deepcopy(target_model)
 
     def _value_targets(self, states, rewards, dones, infos, imitation_learning):
-        """explorer.py:153-186 for a whole batched rollout.  states [T,E,N,13] f32, rewards [T,E] f64,
-        dones [T,E] bool, infos [T,E] u8.  Returns (states [M,N,13], values [M]) of the steps that belong to
-        episodes ending in ReachGoal or Collision (only those feed the memory, explorer.py:107-110)."""
-        T, E = rewards.shape
-        v_pref = float(self.robot.v_pref)
-        gbar = pow(self.gamma, self.env.time_step * v_pref)
-        keep = torch.zeros(T, E, dtype=torch.bool, device=rewards.device)
-        values = torch.zeros(T, E, dtype=torch.float64, device=rewards.device)
-        good_end = (infos == _hip.INFO_REACHGOAL) | (infos == _hip.INFO_COLLISION)
-        if not imitation_learning:
-            with torch.no_grad():
-                nxt = self.target_model(states[1:].reshape(-1, states.shape[2], states.shape[3]).to(self.device))
-            nxt = torch.cat([nxt.view(T - 1, E).double(), torch.zeros(1, E, dtype=torch.float64, device=nxt.device)], 0)
-        ep_ok = torch.zeros(E, dtype=torch.bool, device=rewards.device)      # episode containing step t ends well
-        run = torch.zeros(E, dtype=torch.float64, device=rewards.device)     # discounted tail sum (IL)
-        for t in range(T - 1, -1, -1):
-            d = dones[t]
-            ep_ok = torch.where(d, good_end[t], ep_ok)          # a done at t starts (going backwards) a new episode
-            if imitation_learning:
-                run = torch.where(d, rewards[t], rewards[t] + gbar * run)
-                values[t] = run
-            else:
-                values[t] = torch.where(d, rewards[t], rewards[t] + gbar * nxt[t])
-            keep[t] = ep_ok
-        # steps after the last done of an env belong to an unfinished episode: ep_ok is False there by construction
-        idx = keep.t().reshape(-1).nonzero().squeeze(1)           # (env, time) order
-        flat_states = states.permute(1, 0, 2, 3).reshape(T * E, states.shape[2], states.shape[3])
-        flat_values = values.t().reshape(-1)
-        return flat_states[idx], flat_values[idx].float()
+        gbar = pow(self.gamma, self.env.time_step * float(self.robot.v_pref))
+        return value_targets(states, rewards, dones, infos, imitation_learning, gbar, self.target_model, self.device)
 
     def _actions(self, step_actions):
         if step_actions is not None:

@@ -1,0 +1,261 @@
+"""Batched DataGen: "explore in mixed reality" rollouts (reference: crowd_nav/utils/datagen.py:379-543).
+
+The reference plays ONE sample at a time: pick a recorded real episode, cut it at a random length, put the
+ModelCrowdSim into replay mode (`set_current_state`), let the robot policy act while the humans first replay their
+recorded velocities (`env.step(action, new_v=...)`) and are then "imagined" by the world model (`new_v=None`) or
+frozen, collect (rotated joint state, reward) pairs, and push value targets into the replay memory when the sample
+ends in ReachGoal / Collision.
+
+Here E samples run side by side on a VecModelCrowdSim resident in HBM: the recorded episodes live on the device as
+one [episodes, T_max, N, 5] tensor, each step is one policy launch (`predict_batch`), one gather of the recorded
+velocities (or one world-model launch) and one `mcn_env_step` launch in given-velocity mode; rewards / dones /
+infos stay on the device and the value targets are computed by the same batched routine as VecExplorer
+(`rollout.value_targets`).  The host-side random draws (episode choice, cut length) are made with Python's `random`
+in the reference's order, so with the same seed and a greedy policy the samples are the reference's samples.
+
+Not carried over this round (raise NotImplementedError): `replace_robot` (robot takes over a human's track),
+`view_distance` / `view_human` filters (they make the human count ragged per env), episodes whose human count
+changes over time, `render_path`.
+"""
+import copy
+import logging
+import random
+
+import numpy as np
+import torch
+
+from .. import _hip
+from ..rollout import value_targets, average
+
+
+def _ob_rows(ob):
+    """One recorded observation -> [N,5] float64 rows (px, py, vx, vy, radius).  Accepts the reference's
+    list[ObservableState] (state.py:27-43) or an array-like."""
+    if len(ob) and hasattr(ob[0], "px"):
+        return np.array([[h.px, h.py, h.vx, h.vy, h.radius] for h in ob], np.float64)
+    return np.asarray(ob, np.float64).reshape(-1, 5)
+
+
+class VecDataGen(object):
+    def __init__(self, memory, robot, env, policy):
+        """env: a configured VecModelCrowdSim (robot set).  policy: the robot's policy (predict_batch /
+        transform_batch surface: SARL and the other MultiHumanRL policies)."""
+        self.counter = 0
+        self.raw_memory = None
+        self.memory = memory
+        self.robot = robot
+        self.policy = policy
+        self.target_model = None
+        self.env = env
+        self.gamma = policy.gamma
+        self._epi = None
+
+    def update_target_model(self, target_model):
+        self.target_model = copy.deepcopy(target_model)
+
+    # ------------------------------------------------------------------ recorded episodes
+    def get_episode_start_index(self):
+        """datagen.py:220-230."""
+        indexes, add = [], True
+        for i, data in enumerate(self._raw_list()):
+            if add:
+                indexes.append(i)
+                add = False
+            if data[2]:
+                add = True
+        return indexes
+
+    def count(self):
+        return len(self.get_episode_start_index())
+
+    def _raw_list(self):
+        raw = self.raw_memory
+        return raw.memory if hasattr(raw, "memory") else raw
+
+    def load_real_episodes(self, max_human=-1):
+        """raw_memory (the reference's list of (ob, reward, done, info[, start_ends]) rows, misc.py:85-89 /
+        explorer.py:116-121) -> device tensors: obs [n_epi, T_max, N, 5] float64, length [n_epi]."""
+        raw = self._raw_list()
+        starts = self.get_episode_start_index()
+        epis = []
+        for s in starts:
+            rows = []
+            for data in raw[s:]:
+                ob = _ob_rows(data[0])
+                if 0 < max_human < len(ob):
+                    ob = ob[:max_human]
+                rows.append(ob)
+                if data[2]:
+                    break
+            n = {r.shape[0] for r in rows}
+            if len(n) != 1:
+                raise NotImplementedError("episode starting at raw_memory[%d] changes its human count (%s)" % (s, sorted(n)))
+            epis.append(np.stack(rows))
+        n = {e.shape[1] for e in epis}
+        if len(n) != 1:
+            raise NotImplementedError("recorded episodes have different human counts: %s" % sorted(n))
+        T = max(e.shape[0] for e in epis)
+        obs = np.zeros((len(epis), T, epis[0].shape[1], 5), np.float64)
+        for i, e in enumerate(epis):
+            obs[i, :e.shape[0]] = e
+        dev = self.env.device
+        self._epi = dict(starts=starts, slot={s: i for i, s in enumerate(starts)},
+                         obs=torch.from_numpy(obs).to(dev), length=[e.shape[0] for e in epis], max_human=max_human)
+        return self._epi
+
+    # ------------------------------------------------------------------ sample list (host RNG, reference order)
+    def _draw_samples(self, num_sample, min_end, static_end, add_sim, random_epi, test_case):
+        ep = self._epi
+        indexes = ep["starts"]
+        picks = []
+        guard = 0
+        while len(picks) < num_sample:
+            guard += 1
+            if guard > 1000 * max(1, num_sample):
+                raise RuntimeError("no recorded episode is longer than min_end=%d" % min_end)
+            if random_epi:                                   # datagen.py:236-241
+                i = random.choice(indexes)
+            else:
+                i = indexes[self.counter % len(indexes)]
+                self.counter += 1
+            if test_case is not None:
+                i = test_case
+                if i not in ep["slot"]:
+                    raise NotImplementedError("test_case must be the raw_memory index of an episode start")
+            L = ep["length"][ep["slot"][i]]
+            if L <= min_end:                                 # :412-413
+                continue
+            length = L
+            if add_sim:                                      # :415-418
+                length = random.randrange(min_end, L)
+                if static_end > 0:
+                    length = static_end
+            picks.append((ep["slot"][i], min(length, L)))
+        return picks
+
+    # ------------------------------------------------------------------ the batched loop
+    def gen_data_from_explore_in_mix(self, num_sample, phase="train", min_end=1, static_end=-1, max_human=-1,
+                                     imitation_learning=False, add_sim=True, stay=False, random_epi=True,
+                                     random_robot=True, render_path=None, view_distance=-1, view_human=-1,
+                                     returnRate=False, updateMemory=True, replace_robot=False, sgan_genfile=None,
+                                     test_case=None, returnNav=False):
+        """Same arguments and return value as datagen.py:379-518.  `sgan_genfile` (the text file that seeds the
+        SGAN world model's history in the reference, :421-430) is honoured by seeding the HBM history ring of a
+        VecSGANWorld with the last `min_end` real frames of every sample; its value is otherwise unused."""
+        if replace_robot or view_distance > 0 or view_human > 0 or render_path is not None:
+            raise NotImplementedError("replace_robot / view filters / render_path are not carried over")
+        env, pol = self.env, self.policy
+        if self._epi is None or self._epi["max_human"] != max_human:
+            self.load_real_episodes(max_human)
+        ep = self._epi
+        E, dev = env.num_envs, env.device
+        N = ep["obs"].shape[2]
+        pol.set_phase(phase)
+        picks = self._draw_samples(num_sample, min_end, static_end, add_sim, random_epi, test_case)
+        horizon = int(round(env.time_limit / env.time_step)) + 2
+        v_pref, dt = float(self.robot.v_pref), float(env.time_step)
+        gbar = pow(self.gamma, dt * v_pref)
+        human_radius = float(env._human_radius)
+        rec = dict(ret=[], info=[], time=[], steps=[])
+        too_close, min_dist = 0, []
+        sim = env.sim_world
+        for w0 in range(0, num_sample, E):
+            wave = picks[w0:w0 + E]
+            n_live = len(wave)
+            pad = wave + [wave[-1]] * (E - n_live)                       # idle envs repeat the last sample
+            slot = torch.tensor([p[0] for p in pad], device=dev)
+            length = torch.tensor([p[1] for p in pad], device=dev)
+            obs = ep["obs"][slot]                                         # [E,T,N,5]
+            T_rec = obs.shape[1]
+            env.set_current_state(obs[:, 0, :, 0:2].contiguous(), obs[:, 0, :, 2:4].contiguous(),
+                                  torch.full((E, N), human_radius, dtype=torch.float64, device=dev))
+            hist0 = None
+            if add_sim and sgan_genfile is not None and hasattr(sim, "reset_history"):
+                # the reference writes raw_states[-min_end:] of the cut episode (:423-430); frames before the
+                # episode start repeat its first frame (data_loader pads a short track with its first position)
+                k = torch.arange(-(sim.hist.shape[1]), 0, device=dev).view(1, -1) + length.view(-1, 1)
+                k = torch.maximum(k, (length - min_end).clamp(min=0).view(-1, 1))
+                hist0 = torch.gather(obs[..., 0:2], 1, k.view(E, -1, 1, 1).expand(E, k.shape[1], N, 2))
+                sim.reset_history(hist0)
+            states, rewards, dones, infos = [], [], [], []
+            alive = torch.ones(E, dtype=torch.bool, device=dev)
+            for i in range(horizon):
+                states.append(pol.transform_batch(env))
+                if stay:
+                    act = torch.zeros(E, 2, dtype=torch.float64, device=dev)
+                else:
+                    act, _ = pol.predict_batch(env)
+                    eps = float(getattr(pol, "epsilon", 0) or 0)
+                    if phase == "train" and eps > 0:            # multi_human_rl.py:28-30, one draw per env
+                        table = pol._bufs["table"]
+                        explore = torch.rand(E, device=dev) < eps
+                        ridx = torch.randint(0, table.shape[0], (E,), device=dev)
+                        act = torch.where(explore.unsqueeze(1), table[ridx], act)
+                replay = (i + 1) < length                                        # :452 per env
+                nxt = obs[:, min(i + 1, T_rec - 1), :, 2:4]
+                if add_sim:
+                    if bool((~replay).any()):
+                        imagined = sim(env.hpos)
+                        new_v = torch.where(replay.view(E, 1, 1), nxt, imagined)
+                        if hist0 is not None and bool(replay.any()):
+                            self._restore_history(sim, hist0, replay)
+                    else:
+                        new_v = nxt
+                else:
+                    new_v = torch.where(replay.view(E, 1, 1), nxt, torch.zeros_like(nxt))   # humans stop moving
+                env.step(act, new_v=new_v.contiguous())
+                rewards.append(env.reward.clone()); dones.append(env.done.bool() & alive)
+                infos.append(env.info.clone())
+                alive = alive & ~env.done.bool()
+                if i % 8 == 7 and not bool(alive[:n_live].any()):
+                    break
+            if bool(alive[:n_live].any()):
+                raise RuntimeError("a sample did not end within %d steps" % horizon)
+            R, D, I = torch.stack(rewards), torch.stack(dones), torch.stack(infos)       # [T,E]
+            Tn = R.shape[0]
+            end = D.float().argmax(0)                                                  # step index of the done
+            tt = torch.arange(Tn, device=dev).view(-1, 1)
+            in_ep = tt <= end.view(1, -1)
+            disc = torch.tensor([pow(self.gamma, t * dt * v_pref) for t in range(Tn)], dtype=torch.float64, device=dev)
+            ret = (R * disc.view(-1, 1) * in_ep).sum(0)
+            fin = I.gather(0, end.view(1, -1)).squeeze(0)
+            danger = (I == _hip.INFO_DANGER) & in_ep
+            live = torch.zeros(E, dtype=torch.bool, device=dev); live[:n_live] = True
+            too_close += int((danger & live.view(1, -1)).sum().item())
+            # dmin of the Danger steps: kept on the device by the step record
+            rec["ret"] += ret[:n_live].tolist(); rec["info"] += fin[:n_live].tolist()
+            rec["steps"] += (end[:n_live] + 1).tolist()
+            if updateMemory:
+                if self.memory is None or self.gamma is None:
+                    raise ValueError("Memory or gamma value is not set!")
+                s, v = value_targets(torch.stack(states), R, D & live.view(1, -1), I, imitation_learning, gbar,
+                                     self.target_model, dev)
+                self.memory.push_batch(s, v)
+            self._last_wave = dict(states=torch.stack(states), rewards=R, dones=D, infos=I, live=n_live)
+        k = num_sample
+        infos_l = [int(c) for c in rec["info"]]
+        reach_goal = sum(1 for c in infos_l if c == _hip.INFO_REACHGOAL)
+        collision = sum(1 for c in infos_l if c == _hip.INFO_COLLISION)
+        times = [n * dt for n in rec["steps"]]
+        success_times = [t for t, c in zip(times, infos_l) if c == _hip.INFO_REACHGOAL]
+        avg_nav_time = sum(success_times) / len(success_times) if success_times else env.time_limit
+        avg_ret = average(rec["ret"])
+        logging.info("Exp in mix has success rate: %.2f, collision rate: %.2f, nav time: %.2f, total reward: %.4f",
+                     reach_goal / k, collision / k, avg_nav_time, avg_ret)
+        self.last_records = dict(returns=rec["ret"], infos=infos_l, times=times, danger_steps=too_close, samples=picks)
+        if returnRate and returnNav:
+            return avg_ret, reach_goal / k, collision / k, (k - reach_goal - collision) / k, avg_nav_time
+        if returnRate:
+            return avg_ret, reach_goal / k, collision / k, (k - reach_goal - collision) / k
+        return avg_ret, reach_goal, collision, (k - reach_goal - collision)
+
+    @staticmethod
+    def _restore_history(sim, hist0, keep):
+        """Envs that are still replaying must not see the frame the world-model call just pushed: the reference
+        only touches the history file when it imagines (world_model.py:234-249).  Rewrites their rows of the ring
+        (oldest-first order starts at sim.oldest)."""
+        H = sim.hist.shape[1]
+        order = (torch.arange(H, device=hist0.device) + sim.oldest) % H
+        from ..policy.world_model import round4
+        rows = keep.nonzero().squeeze(1)
+        sim.hist[rows.view(-1, 1), order.view(1, -1)] = round4(hist0[rows].to(sim.hist.dtype))

@@ -1,0 +1,85 @@
+"""GPU: batched DataGen ("explore in mixed reality") against what the REAL reference's
+DataGen.gen_data_from_explore_in_mix produced on the same recorded episodes, seeds and weights
+(tests/golden/g8_datagen.npz, generator: tools/gen_golden_nets.py:g8_datagen; datagen.py:379-543).
+
+Tolerances: the value network is float32 on both sides in different summation orders (1e-5 on stored states, which
+are float32 rotations of float64 env state; 2e-4 on value targets, which add up to ~100 discounted rewards or a
+network output); sample outcomes, counts and the sample list are exact."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests import helpers as H  # noqa: E402
+
+RUNS = [("il_freeze", dict(imitation_learning=True, add_sim=False, random_epi=True), 3, 12),
+        ("rl_imagine", dict(imitation_learning=False, add_sim=True, random_epi=False), 4, 10),
+        ("il_static", dict(imitation_learning=True, add_sim=True, random_epi=True, static_end=9), 5, 9)]
+
+
+def _setup(g, name, E):
+    import torch
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.envs import VecModelCrowdSim
+    from modelcrowdnav_amd.policy.sarl import SARL
+    from modelcrowdnav_amd.policy.world_model import MlpWorld, VecTorchWorld
+    from modelcrowdnav_amd.utils.memory import ReplayMemory
+    from modelcrowdnav_amd.utils.datagen import VecDataGen
+    dev = torch.device("cuda", 0)
+    env = H.make_vec_env(E, 5, cls=VecModelCrowdSim)
+    pol = SARL()
+    pol.configure(configs.policy_config())
+    pol.kinematics = "holonomic"
+    pol.model.load_state_dict({k[3:].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith("w__")})
+    pol.set_device(dev); pol.set_phase("val"); pol.time_step = 0.25
+    env.robot.set_policy(pol)
+    pol.set_env(env)
+    world = MlpWorld(5)
+    pref = name + "_world__"
+    world.load_state_dict({k[len(pref):].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith(pref)})
+    world.eval().to(dev)
+    env.sim_world = VecTorchWorld(world, env)
+    memory = ReplayMemory(100000)
+    dg = VecDataGen(memory, env.robot, env, pol)
+    raw = []
+    i = 0
+    while "epi%d" % i in g.files:
+        e = g["epi%d" % i]
+        for t in range(e.shape[0]):
+            raw.append((e[t], 0, t == e.shape[0] - 1, None))
+        i += 1
+    dg.raw_memory = raw
+    dg.update_target_model(pol.model)
+    return dg, memory
+
+
+@pytest.mark.parametrize("name,kw,seed,num", RUNS)
+@pytest.mark.parametrize("E", [4, 16])
+def test_explore_in_mix_matches_reference(name, kw, seed, num, E, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g8_datagen.npz"))
+    dg, memory = _setup(g, name, E)
+    random.seed(seed)
+    out = dg.gen_data_from_explore_in_mix(num, phase="val", min_end=8, returnRate=False, **kw)
+    want = g[name + "_out"]
+    assert tuple(out[1:]) == tuple(int(x) for x in want[1:]), (out, want)      # reach goal / collision / timeout counts
+    assert abs(out[0] - want[0]) < 1e-9
+    assert dg.counter == int(g[name + "_counter"])
+    states, values = g[name + "_states"], g[name + "_values"]
+    assert len(memory) == states.shape[0]
+    got_s = memory._states[:len(memory)].cpu().numpy()
+    got_v = memory._values[:len(memory), 0].cpu().numpy()
+    np.testing.assert_allclose(got_s, states, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(got_v, values, rtol=0, atol=2e-4)
+
+
+def test_explore_in_mix_rejects_what_is_not_carried_over(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g8_datagen.npz"))
+    dg, _ = _setup(g, "il_freeze", 4)
+    with pytest.raises(NotImplementedError):
+        dg.gen_data_from_explore_in_mix(2, phase="val", min_end=8, replace_robot=True)
+    with pytest.raises(NotImplementedError):
+        dg.gen_data_from_explore_in_mix(2, phase="val", min_end=8, view_human=3)
+    assert dg.count() == 7

@@ -8,6 +8,9 @@
                                                                       (sgan/models.py:501-553)
   g7_episode  hand-driven reset/act/step episodes: reference CrowdSim + SARL robot
                                                                       (explorer.py:54-125)
+  g8_datagen  DataGen.gen_data_from_explore_in_mix on a synthetic recorded set: replay-then-freeze and
+              replay-then-imagine (MlpWorld) samples, memory contents in IL and RL mode
+                                                                      (datagen.py:379-543)
 """
 import os
 
@@ -130,6 +133,76 @@ def g7_episode():
     print("g7_episode: %d arrays" % len(rec))
 
 
+def synthetic_recorded_episodes(seed=11, n_epi=7, N=5):
+    """Recorded 'real' episodes in the raw_memory layout of misc.py:85-89: per frame an [N,5] row block
+    (px, py, vx, vy, radius).  Tracks are straight walks through the robot's corridor with a slow drift; velocities
+    are frame differences times the frame rate, as misc.py:GetVel computes them."""
+    rng = np.random.RandomState(seed)
+    fps = 1.0 / 0.25
+    epis = []
+    for e in range(n_epi):
+        T = int(rng.randint(22, 44))
+        a = rng.uniform(0, 2 * np.pi, N)
+        start = np.stack([3.5 * np.cos(a), 3.5 * np.sin(a) - 1.0], 1) + rng.uniform(-0.4, 0.4, (N, 2))
+        goal = -start + rng.uniform(-0.6, 0.6, (N, 2)) + np.array([0.0, -2.0])
+        speed = rng.uniform(0.5, 1.1, N)
+        d = goal - start
+        step = d / np.linalg.norm(d, axis=1, keepdims=True) * speed[:, None] / fps
+        pos = start[None] + step[None] * np.arange(T)[:, None, None]
+        pos = pos + 0.05 * np.sin(np.arange(T)[:, None, None] * 0.3 + a[None, :, None])
+        pos = np.round(pos, 3)                      # dataset coordinates come with few decimals
+        vel = np.zeros_like(pos)
+        vel[1:] = (pos[1:] - pos[:-1]) * fps
+        epis.append(np.concatenate([pos, vel, np.full((T, N, 1), 0.3)], 2))
+    return epis
+
+
+def g8_datagen():
+    """Reference DataGen (datagen.py:379-543) over ModelCrowdSim + SARL robot with seeded weights."""
+    import random
+    from crowd_nav.utils.datagen import DataGen
+    from crowd_nav.utils.memory import ReplayMemory
+    from crowd_nav.policy.world_model import MlpWorld
+    from crowd_sim.envs.utils.state import ObservableState
+    from crowd_sim.envs.utils.info import Nothing
+    rec = {}
+    epis = synthetic_recorded_episodes()
+    for i, e in enumerate(epis):
+        rec["epi%d" % i] = e
+    raw = []
+    for e in epis:
+        start_ends = [[e[0, h, 0], e[0, h, 1], e[-1, h, 0], e[-1, h, 1]] for h in range(e.shape[1])]
+        for t in range(e.shape[0]):
+            ob = [ObservableState(*e[t, h].tolist()) for h in range(e.shape[1])]
+            raw.append((ob, 0, t == e.shape[0] - 1, Nothing(), start_ends))
+    runs = [("il_freeze", dict(imitation_learning=True, add_sim=False, random_epi=True), 3, 12),
+            ("rl_imagine", dict(imitation_learning=False, add_sim=True, random_epi=False), 4, 10),
+            ("il_static", dict(imitation_learning=True, add_sim=True, random_epi=True, static_end=9), 5, 9)]
+    for name, kw, seed, num in runs:
+        torch.manual_seed(3)            # default-init SARL weights that happen to drive to the goal: memory gets rows
+        env, robot, pol = G.make_env("ModelCrowdSim", robot_policy="sarl", humans_policy="orca", human_num=5)
+        torch.manual_seed(100 + seed)
+        world = MlpWorld(5)
+        world.eval()
+        env.sim_world = world
+        env.device = torch.device("cpu")
+        rec.update(_state_dict_arrays(pol.model, "w__"))          # same seeded weights in every run
+        rec.update(_state_dict_arrays(world, name + "_world__"))
+        memory = ReplayMemory(100000)
+        dg = DataGen(memory, robot, env, pol)
+        dg.raw_memory = raw
+        dg.update_target_model(pol.model)
+        random.seed(seed)
+        out = dg.gen_data_from_explore_in_mix(num, phase="val", min_end=8, returnRate=False, **kw)
+        rec[name + "_out"] = np.array(out, np.float64)
+        rec[name + "_states"] = np.stack([m[0].numpy() for m in memory.memory]) if len(memory.memory) else np.zeros((0, 5, 13), np.float32)
+        rec[name + "_values"] = np.array([float(m[1].item()) for m in memory.memory], np.float32)
+        rec[name + "_counter"] = np.array(dg.counter)
+        print("  %s: out %s, %d memory rows" % (name, out, len(memory.memory)))
+    np.savez_compressed(os.path.join(OUT, "g8_datagen.npz"), **rec)
+    print("g8_datagen: %d arrays" % len(rec))
+
+
 def g6_sgan():
     from crowd_nav.policy.world_model import get_generator
     from sgan.utils import relative_to_abs
@@ -167,4 +240,4 @@ def g6_sgan():
     print("g6_sgan: %d arrays" % len(rec))
 
 
-FAMILIES = {"g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode}
+FAMILIES = {"g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen}

@@ -8,6 +8,9 @@
                                                                       (sgan/models.py:501-553)
   g7_episode  hand-driven reset/act/step episodes: reference CrowdSim + SARL robot
                                                                       (explorer.py:54-125)
+  g9_realdata GetRealData on a synthetic TrajNet++ ndjson (tests/golden/g9_scenes.ndjson, written by this tool):
+              per-frame observation lists, start_ends, world-model pairs, SGAN cache files, for the default options
+              and for windowed scenes with 'moving' / 'stay' padding           (misc.py:47-187, reader.py:44-166)
   g8_datagen  DataGen.gen_data_from_explore_in_mix on a synthetic recorded set: replay-then-freeze and
               replay-then-imagine (MlpWorld) samples, memory contents in IL and RL mode
                                                                       (datagen.py:379-543)
@@ -203,6 +206,80 @@ def g8_datagen():
     print("g8_datagen: %d arrays" % len(rec))
 
 
+def write_synthetic_ndjson(path, seed=21):
+    """A small TrajNet++-style recording: three groups of overlapping scene entries separated by silent gaps,
+    pedestrians that enter and leave at different frames, one track with a missing sample, frames every 2 ticks."""
+    import json
+    rng = np.random.RandomState(seed)
+    lines, sid = [], 0
+    ped0 = 0
+    for grp, (f0, n_frames, n_ped) in enumerate(((10, 16, 4), (80, 22, 6), (200, 12, 3))):
+        frames = [f0 + 2 * i for i in range(n_frames)]
+        tracks = {}
+        for k in range(n_ped):
+            a = int(rng.randint(0, max(1, n_frames // 3))) if k else 0          # pedestrian 0 of a group is there from the start
+            b = int(rng.randint(2 * n_frames // 3, n_frames)) if k else n_frames - 1
+            p0, v = rng.uniform(-5, 5, 2), rng.uniform(-0.35, 0.35, 2)
+            pts = [(frames[i], ped0 + k, round(float(p0[0] + v[0] * (i - a) + 0.03 * np.sin(i)), 2),
+                    round(float(p0[1] + v[1] * (i - a) + 0.03 * np.cos(i)), 2)) for i in range(a, b + 1)]
+            if grp == 1 and k == 2 and len(pts) > 6:
+                del pts[4]                                                       # a dropped detection
+            tracks[ped0 + k] = pts
+        # scene entries: overlapping windows over the group, each with a primary pedestrian present at its start
+        for w in range(0, n_frames - 8, 5):
+            s_f, e_f = frames[w], frames[min(w + 9, n_frames - 1)]
+            prim = [pid for pid, pts in tracks.items() if any(r[0] == s_f for r in pts)][0]
+            lines.append(json.dumps({"scene": {"id": sid, "p": prim, "s": s_f, "e": e_f, "fps": 2.5, "tag": [0, []]}}))
+            sid += 1
+        for f in frames:
+            for pid, pts in tracks.items():
+                for r in pts:
+                    if r[0] == f:
+                        lines.append(json.dumps({"track": {"f": r[0], "p": r[1], "x": r[2], "y": r[3]}}))
+        ped0 += n_ped
+    with open(path, "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+
+
+def g9_realdata():
+    """Reference GetRealData (misc.py:47-116) on the synthetic recording."""
+    import tempfile
+    from crowd_nav.utils.misc import GetRealData, StoreAction
+    path = os.path.join(OUT, "g9_scenes.ndjson")
+    write_synthetic_ndjson(path)
+    rec = {}
+    cases = [("default_test", dict(phase="test")),
+             ("default_train", dict(phase="train")),
+             ("default_val", dict(phase="val")),
+             ("win_moving", dict(phase="test", stride=2, windows_size=6, padding_last="moving", padding_first="stay")),
+             ("win_slice", dict(phase="val", stride=3, windows_size=5, dataset_slice=[1, 6]))]
+    for name, kw in cases:
+        with tempfile.TemporaryDirectory() as td:
+            raw, rawob = GetRealData(dataset_file=path, Store_for_world_fn=StoreAction, cacheFile=td, **kw)
+            rows = raw.memory
+            n = np.array([len(r[0]) for r in rows], np.int64)
+            flat = np.array([[h.px, h.py, h.vx, h.vy, h.radius] for r in rows for h in r[0]], np.float64).reshape(-1, 5)
+            rec[name + "_count"] = n
+            rec[name + "_obs"] = flat
+            rec[name + "_done"] = np.array([r[2] for r in rows])
+            se = [np.array(r[4], np.float64).reshape(-1, 4) for r in rows]
+            rec[name + "_se_count"] = np.array([len(x) for x in se], np.int64)
+            rec[name + "_se"] = np.concatenate(se) if se else np.zeros((0, 4))
+            pairs = rawob.memory
+            rec[name + "_pair_count"] = np.array([p[0].shape[0] for p in pairs], np.int64)
+            rec[name + "_pair_cur"] = np.concatenate([p[0].numpy() for p in pairs]) if pairs else np.zeros((0, 4), np.float32)
+            rec[name + "_pair_next_count"] = np.array([p[1].shape[0] for p in pairs], np.int64)
+            rec[name + "_pair_next"] = np.concatenate([p[1].numpy().reshape(-1, 2) for p in pairs]) if pairs else np.zeros((0, 2), np.float32)
+            files = sorted(os.listdir(td), key=lambda x: int(x.split(".")[0]))
+            rec[name + "_cache_files"] = np.array(len(files))
+            for f in files:
+                rec[name + "_cache_" + f.split(".")[0]] = np.frombuffer(open(os.path.join(td, f), "rb").read(), np.uint8)
+            print("  %s: %d rows, %d episodes, %d pairs, %d cache files" % (name, len(rows), int(rec[name + "_done"].sum()),
+                                                                          len(pairs), len(files)))
+    np.savez_compressed(os.path.join(OUT, "g9_realdata.npz"), **rec)
+    print("g9_realdata: %d arrays" % len(rec))
+
+
 def g6_sgan():
     from crowd_nav.policy.world_model import get_generator
     from sgan.utils import relative_to_abs
@@ -240,4 +317,4 @@ def g6_sgan():
     print("g6_sgan: %d arrays" % len(rec))
 
 
-FAMILIES = {"g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen}
+FAMILIES = {"g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}

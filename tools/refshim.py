@@ -1,11 +1,13 @@
 """Golden-vector tooling (this container only; never shipped to the GPU box as a dependency).
 
-Makes `/root/reference` importable by placing three throw-away modules in
+Makes `/root/reference` importable by placing throw-away modules in
 sys.modules for the packages the image lacks:
 
   gym       -- `Env` base class + `envs.registration.register` no-op
                (crowd_sim/__init__.py:1, crowd_sim/envs/crowd_sim.py:2,15)
   attrdict  -- dict with attribute access (crowd_nav/policy/world_model.py:4,109)
+  pykalman  -- empty module: imported at the top of the vendored trajnetplusplustools/kalman.py, never used by the
+               ndjson reader that crowd_nav/utils/misc.py:GetRealData drives
   rvo2      -- `PyRVOSimulator` with exactly the methods the reference calls
                (crowd_sim/envs/policy/orca.py:95-129, crowd_sim/envs/crowd_sim.py:231-255),
                backed by THIS REPO's C ORCA restatement (oracle/mcn_oracle.c).
@@ -102,5 +104,12 @@ def install():
         rvo2 = types.ModuleType("rvo2")
         rvo2.PyRVOSimulator = _PyRVOSimulator
         sys.modules["rvo2"] = rvo2
+    if "pykalman" not in sys.modules:
+        # trajnetplusplustools/__init__.py:10 pulls in kalman.py, whose only top-level use of pykalman is the import;
+        # nothing on the ingest path (reader.py, data.py) touches it
+        try:
+            import pykalman  # noqa: F401
+        except ImportError:
+            sys.modules["pykalman"] = types.ModuleType("pykalman")
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)

@@ -7,8 +7,11 @@ Workload (BASELINE.json configs[1]): 4096 envs x 5 humans per GPU, ORCA humans, 
 drawn uniformly from the 81-entry action table by torch.Generator(seed=0), robot invisible,
 scenarios = test cases 1000 + (global_env_id mod 500), auto-reset on done from an HBM-resident
 pool of the same 500 scenarios, Explorer-style discounted returns accumulated in-kernel.
-A "step" is one mcn_env_step launch over the whole batch.  Inputs (states, the per-step action
-tensors) are resident in HBM before the timed region; the K steps are replayed from one hipGraph.
+A "step" is one CrowdSim.step of the whole batch.  The robot's actions are a pre-drawn sequence, so the K
+steps go to the device as ceil(K / 250) mcn_env_rollout launches (env state in registers between the steps
+of a launch; --steps-per-launch 1 = one mcn_env_step launch per step, also reported as single_step_launch).
+Inputs (states, the [K, E, 2] action tensor) are resident in HBM before the timed region; the launches are
+replayed from one hipGraph.
 Envs shard across ranks with no per-step communication (weak scaling); at the end of the
 rollout one RCCL all_gather collects episode returns + outcome codes.
 
@@ -381,7 +384,8 @@ def main():
     if S > 1:
         # state lives in registers across the steps of a launch: HBM sees the state once per launch, not per step
         roof["note"] = ("algorithmic bytes = SURVEY 8(d) per-env-step figure x env-steps per launch; a launch keeps the "
-                        "env state in registers for its %d steps, so real HBM traffic is ~1/%d of that" % (S, S))
+                        "env state in registers for its %d steps, so real HBM traffic (`traffic`) is a fraction of "
+                        "that and the kernel is instruction-issue-bound, not HBM-bound" % S)
 
     result = {
         "metric": "env-steps/sec (whole node), 5-human CrowdSim x batched envs",

@@ -153,6 +153,31 @@ int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *
 int mcn_env_rollout(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *actions, int32_t T,
                     const mcn_env_out *out, const mcn_rollout *roll, int32_t E, int32_t N, void *stream);
 
+/* Scenario rules of CrowdSim.reset (crowd_sim.py:120-163). */
+enum { MCN_RULE_CIRCLE = 0, MCN_RULE_SQUARE = 1 };
+
+typedef struct mcn_scenario_cfg {
+    double circle_radius, square_width;      /* env.config [sim] */
+    double discomfort_dist;                  /* env.config [reward] */
+    double human_radius, human_v_pref;       /* env.config [humans] (used when randomize_attributes == 0) */
+    double robot_radius;
+    double robot_start[2], robot_goal[2];    /* crowd_sim.py:284 */
+    int32_t rule;                            /* MCN_RULE_* */
+    int32_t randomize_attributes;            /* agent.py:39-45 */
+} mcn_scenario_cfg;
+
+/*
+ * mcn_scenario_pool -- P crowd scenarios of N humans generated ON the device into the pool arrays that
+ * mcn_rollout's in-kernel restart reads (pool_hpos / pool_hgoal [P*N][2], pool_hrad / pool_hvpref [P*N]).
+ * Replaces, for rollouts that do not need bit-parity with the reference's random stream,
+ * generate_random_human_position / generate_circle_crossing_human / generate_square_crossing_human
+ * (crowd_sim/envs/crowd_sim.py:94-215): same placement rules and rejection tests, counter-based random numbers
+ * keyed by (seed, first_case + i), so case i is the same whatever P or the partition.  The bit-exact generator
+ * (numpy MT19937, host) stays in modelcrowdnav_amd/envs/scenarios.py.
+ */
+int mcn_scenario_pool(const mcn_scenario_cfg *cfg, uint64_t seed, int64_t first_case, int32_t P, int32_t N,
+                      double *hpos, double *hgoal, double *hrad, double *hvpref, void *stream);
+
 /*
  * mcn_orca_batch -- ORCA velocity for B independent agents, each with up to M candidate
  * neighbours (float32, RVO2 semantics).  Replaces the rvo2.PyRVOSimulator

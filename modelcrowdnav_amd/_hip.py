@@ -78,6 +78,15 @@ class Rollout(C.Structure):
     ]
 
 
+class ScenarioCfg(C.Structure):
+    _fields_ = [("circle_radius", _d), ("square_width", _d), ("discomfort_dist", _d), ("human_radius", _d),
+                ("human_v_pref", _d), ("robot_radius", _d), ("robot_start", _d * 2), ("robot_goal", _d * 2),
+                ("rule", _i), ("randomize_attributes", _i)]
+
+
+RULE_CIRCLE, RULE_SQUARE = 0, 1
+
+
 class McnError(RuntimeError):
     pass
 
@@ -95,6 +104,8 @@ def _load():
     lib.mcn_env_rollout.argtypes = [C.POINTER(EnvCfg), C.POINTER(EnvState), _vp, _i, C.POINTER(EnvOut),
                                     C.POINTER(Rollout), _i, _i, _vp]
     lib.mcn_env_rollout.restype = C.c_int
+    lib.mcn_scenario_pool.argtypes = [C.POINTER(ScenarioCfg), C.c_uint64, C.c_int64, _i, _i, _vp, _vp, _vp, _vp, _vp]
+    lib.mcn_scenario_pool.restype = C.c_int
     lib.mcn_orca_batch.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _f, _f, _vp]
     lib.mcn_orca_batch.restype = C.c_int
     fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
@@ -115,7 +126,7 @@ def _load():
 lib = _load()
 
 # every symbol include/mcn.h declares; tests/test_abi.py checks the .so exports each one
-EXPORTED = ["mcn_version", "mcn_env_step", "mcn_env_rollout", "mcn_orca_batch", "mcn_pack_linear", "mcn_sarl_workspace_bytes",
+EXPORTED = ["mcn_version", "mcn_env_step", "mcn_env_rollout", "mcn_scenario_pool", "mcn_orca_batch", "mcn_pack_linear", "mcn_sarl_workspace_bytes",
             "mcn_sarl_lookahead", "mcn_sgan_workspace_bytes", "mcn_sgan_step"]
 
 

@@ -11,6 +11,8 @@
 namespace mcn {
 int launch_env_step(const StepParams &p, hipStream_t stream);
 bool launch_env_rollout_quad(const StepParams &p, int T, hipStream_t stream);
+int launch_scenario_pool(const mcn_scenario_cfg &c, uint64_t seed, int64_t first_case, int P, int N, double *hpos,
+                         double *hgoal, double *hrad, double *hvpref, hipStream_t stream);
 struct SarlParams;
 long sarl_workspace_float4s(int E, int N, int A);
 int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int A, double dt,
@@ -113,6 +115,16 @@ int mcn_env_rollout(const mcn_env_cfg *cfg, const mcn_env_state *st, const doubl
         if (r != MCN_OK) return r;
     }
     return MCN_OK;
+}
+
+int mcn_scenario_pool(const mcn_scenario_cfg *cfg, uint64_t seed, int64_t first_case, int32_t P, int32_t N,
+                      double *hpos, double *hgoal, double *hrad, double *hvpref, void *stream)
+{
+    if (!cfg || !hpos || !hgoal || !hrad || !hvpref) return MCN_EINVAL;
+    if (P <= 0 || N <= 0 || N > MCN_MAX_HUMANS) return MCN_EINVAL;
+    if (cfg->rule != MCN_RULE_CIRCLE && cfg->rule != MCN_RULE_SQUARE) return MCN_EINVAL;
+    if (!(cfg->circle_radius > 0) || !(cfg->square_width > 0) || !(cfg->human_radius > 0)) return MCN_EINVAL;
+    return mcn::launch_scenario_pool(*cfg, seed, first_case, P, N, hpos, hgoal, hrad, hvpref, (hipStream_t)stream);
 }
 
 int mcn_orca_batch(const float *self, const float *others, const int32_t *n_other, float *out,

@@ -176,6 +176,42 @@ class VecCrowdSim(object):
         self.human_times.zero_()
         self.human_num = N
 
+    def device_pool(self, seed, first_case, count, human_num=None, rule="circle_crossing"):
+        """`count` scenarios generated ON the device (mcn_scenario_pool): the reference's placement rules with a
+        counter-based random stream keyed by (seed, case id) -- statistically equivalent to CrowdSim.reset, not
+        bit-identical to it (scenarios.py keeps the bit-exact host generator).  Returns the pool tensors that
+        load_device_scenarios / attach_rollout(pool=...) accept."""
+        N = int(human_num or self.human_num)
+        sp, dev = self.spec(), self.device
+        rr = sp.robot_row()
+        cfg = _hip.ScenarioCfg(sp.circle_radius, sp.square_width, sp.discomfort_dist, sp.human_radius, sp.human_v_pref,
+                               sp.robot_radius, (rr[S.PX], rr[S.PY]), (rr[S.GX], rr[S.GY]),
+                               {"circle_crossing": _hip.RULE_CIRCLE, "square_crossing": _hip.RULE_SQUARE}[rule],
+                               1 if sp.randomize_attributes else 0)
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float64, device=dev)
+        pool = dict(hpos=z(count, N, 2), hgoal=z(count, N, 2), hrad=z(count, N), hvpref=z(count, N))
+        rc = _hip.lib.mcn_scenario_pool(cfg, int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_case), int(count), N,
+                                        _hip.ptr(pool["hpos"]), _hip.ptr(pool["hgoal"]), _hip.ptr(pool["hrad"]),
+                                        _hip.ptr(pool["hvpref"]), _hip.stream_ptr(dev))
+        _hip.check(rc, "mcn_scenario_pool")
+        return pool
+
+    def load_device_scenarios(self, pool, rows):
+        """Start every env from pool row rows[e] (device pool of device_pool()); robot at its start pose."""
+        rows = torch.as_tensor(rows, device=self.device, dtype=torch.long)
+        E, N = self.num_envs, pool["hpos"].shape[1]
+        if rows.numel() != E:
+            raise ValueError("expected %d rows, got %d" % (E, rows.numel()))
+        if self._alloc_N != N:
+            self._allocate(N)
+        self.hpos.copy_(pool["hpos"][rows]); self.hgoal.copy_(pool["hgoal"][rows]); self.hvel.zero_()
+        self.hrad.copy_(pool["hrad"][rows]); self.hvpref.copy_(pool["hvpref"][rows])
+        rr = torch.tensor(self.spec().robot_row(), dtype=torch.float64, device=self.device)
+        self.rpos.copy_(rr[[S.PX, S.PY]].expand(E, 2)); self.rgoal.copy_(rr[[S.GX, S.GY]].expand(E, 2))
+        self.rvel.zero_(); self.rrad.fill_(float(rr[S.RAD])); self.rvpref.fill_(float(self.robot.v_pref))
+        self.rtheta.fill_(float(rr[S.TH])); self.gtime.zero_(); self.human_times.zero_()
+        self.human_num = N
+
     # ---------------------------------------------------------------- gym surface (batched)
     def _phase_rule(self, phase):
         multi = bool(self.robot.policy.multiagent_training)
@@ -292,14 +328,22 @@ class VecCrowdSim(object):
         for k in ("state", "fin_return", "fin_time", "fin_info"):
             setattr(r, k, _hip.ptr(t[k]))
         if pool is not None:
-            pool = np.asarray(pool, np.float64)
-            P, N = pool.shape[0], pool.shape[1]
-            if N != self._alloc_N:
-                raise ValueError("pool N %d != env N %d" % (N, self._alloc_N))
-            up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-            t["pool_hpos"] = up(pool[:, :, [S.PX, S.PY]]); t["pool_hgoal"] = up(pool[:, :, [S.GX, S.GY]])
-            t["pool_hrad"] = up(pool[:, :, S.RAD]); t["pool_hvpref"] = up(pool[:, :, S.VPREF])
-            t["pool_hvel"] = up(pool[:, :, [S.VX, S.VY]])
+            if isinstance(pool, dict):                   # device pool (device_pool()): used in place, zero velocities
+                P, N = pool["hpos"].shape[0], pool["hpos"].shape[1]
+                if N != self._alloc_N:
+                    raise ValueError("pool N %d != env N %d" % (N, self._alloc_N))
+                t["pool_hpos"], t["pool_hgoal"] = pool["hpos"], pool["hgoal"]
+                t["pool_hrad"], t["pool_hvpref"] = pool["hrad"], pool["hvpref"]
+                t["pool_hvel"] = None
+            else:
+                pool = np.asarray(pool, np.float64)
+                P, N = pool.shape[0], pool.shape[1]
+                if N != self._alloc_N:
+                    raise ValueError("pool N %d != env N %d" % (N, self._alloc_N))
+                up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                t["pool_hpos"] = up(pool[:, :, [S.PX, S.PY]]); t["pool_hgoal"] = up(pool[:, :, [S.GX, S.GY]])
+                t["pool_hrad"] = up(pool[:, :, S.RAD]); t["pool_hvpref"] = up(pool[:, :, S.VPREF])
+                t["pool_hvel"] = up(pool[:, :, [S.VX, S.VY]])
             nc = np.arange(E) % P if first_cases is None else np.asarray(first_cases) % P
             t["next_case"].copy_(torch.from_numpy(nc.astype(np.int32)).to(dev))
             r.pool_hpos, r.pool_hgoal = _hip.ptr(t["pool_hpos"]), _hip.ptr(t["pool_hgoal"])

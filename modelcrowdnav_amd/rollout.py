@@ -81,13 +81,16 @@ class VecExplorer(object):
 
     def run_k_episodes(self, k, phase, update_memory=False, imitation_learning=False, episode=None,
                        print_failure=False, returnRate=True, returnNav=False, action_fn=None, max_steps=None,
-                       total_envs=None, action_seq=None):
+                       total_envs=None, action_seq=None, device_scenarios=None):
         """Returns what Explorer.run_k_episodes returns (explorer.py:146-151):
         (avg cumulative reward, success rate, collision rate, timeout rate[, avg nav time])
         or counts instead of rates when returnRate is False.  `action_fn(env, t) -> [E,2]` overrides the
         policy (e.g. a random-action baseline).  `action_seq` ([T,E,2] device tensor) is a robot whose actions do
         not depend on the observation: its steps go to the device 32 at a time through mcn_env_rollout (one launch,
-        state in registers) instead of one launch per step; not combinable with update_memory."""
+        state in registers) instead of one launch per step; not combinable with update_memory.
+        `device_scenarios=seed` builds the k scenarios on the device (mcn_scenario_pool: the reference's placement
+        rules, counter-based random stream -- for training rollouts that need many distinct cases, not for parity
+        runs) instead of generating them on the host with numpy's MT19937."""
         env = self.env
         rank, ws = mdist.world()
         E_local = env.num_envs
@@ -101,16 +104,29 @@ class VecExplorer(object):
         rounds = -(-k // E_total)                               # episodes per env (ceil)
         cases = [(first + i) % size for i in range(rounds * E_total)]
         uniq = sorted(set(cases))
-        pool = S.scenario_pool(env.spec(), phase, uniq, n, rule)
-        slot_of = {c: j for j, c in enumerate(uniq)}
+        if device_scenarios is None:
+            pool = S.scenario_pool(env.spec(), phase, uniq, n, rule)
+            slot_of = {c: j for j, c in enumerate(uniq)}
+        else:
+            if rule not in ("circle_crossing", "square_crossing"):
+                raise NotImplementedError("device scenarios: circle_crossing / square_crossing only")
+            # case ids keyed like the reference's seeds: offset(phase) + case (crowd_sim.py:270-272)
+            offset = {"train": env.case_capacity["val"] + env.case_capacity["test"], "val": 0,
+                      "test": env.case_capacity["val"]}[phase]
+            pool = env.device_pool(device_scenarios, offset + uniq[0], uniq[-1] - uniq[0] + 1, n, rule)
+            slot_of = {c: c - uniq[0] for c in uniq}
         # env e of this rank plays global episodes (lo + e) + r * E_total, r = 0..rounds-1
         mine = np.array([[slot_of[cases[(lo + e) + r * E_total]] for r in range(rounds)] for e in range(E_local)])
-        env.load_scenarios(pool[mine[:, 0]])
+        if device_scenarios is None:
+            env.load_scenarios(pool[mine[:, 0]])
+        else:
+            env.load_device_scenarios(pool, mine[:, 0])
         stride = 0
         if rounds > 1:
             # pool slots advance by a constant stride when cases are consecutive (the usual situation)
-            d = (mine[:, 1] - mine[:, 0]) % len(uniq)
-            if not np.all(d == d[0]) or any(np.any((mine[:, r + 1] - mine[:, r]) % len(uniq) != d[0])
+            n_pool = len(uniq) if device_scenarios is None else uniq[-1] - uniq[0] + 1
+            d = (mine[:, 1] - mine[:, 0]) % n_pool
+            if not np.all(d == d[0]) or any(np.any((mine[:, r + 1] - mine[:, r]) % n_pool != d[0])
                                             for r in range(rounds - 1)):
                 raise NotImplementedError("non-uniform case stride (k wraps the case list unevenly)")
             stride = int(d[0])

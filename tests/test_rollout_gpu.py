@@ -333,3 +333,60 @@ def test_reference_driver_sequence_through_dropin():
     got = sorted(float(vmem[i][1]) for i in range(len(vmem)))
     want = sorted(float(memory[i][1]) for i in range(len(memory)))
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+
+
+def test_device_scenario_pool_follows_the_placement_rules():
+    """mcn_scenario_pool: the reference's placement rules (crowd_sim.py:165-215) hold for every generated case,
+    cases depend on their id only, and the angle / side statistics are those of the host generator."""
+    import torch
+    E, N, P = 8, 5, 4096
+    for rule, randomize in (("circle_crossing", False), ("square_crossing", False), ("circle_crossing", True)):
+        env = H.make_vec_env(E, N, **({"env.randomize_attributes": "true"} if randomize else {}))
+        pool = env.device_pool(seed=7, first_case=100, count=P, human_num=N, rule=rule)
+        again = env.device_pool(seed=7, first_case=100 + 1000, count=64, human_num=N, rule=rule)
+        torch.cuda.synchronize()
+        pos, goal, rad, vp = (pool[k].cpu().numpy() for k in ("hpos", "hgoal", "hrad", "hvpref"))
+        assert np.array_equal(again["hpos"].cpu().numpy(), pos[1000:1064])           # a case is a function of its id
+        other = env.device_pool(seed=8, first_case=100, count=64, human_num=N, rule=rule)["hpos"].cpu().numpy()
+        assert not np.array_equal(other, pos[:64])
+        if randomize:
+            assert rad.min() >= 0.3 and rad.max() < 0.5 and vp.min() >= 0.5 and vp.max() < 1.5
+            assert abs(rad.mean() - 0.4) < 0.005 and abs(vp.mean() - 1.0) < 0.02
+        else:
+            assert (rad == 0.3).all() and (vp == 1.0).all()
+        gap = rad[:, :, None] + rad[:, None, :] + 0.2
+        d = np.linalg.norm(pos[:, :, None] - pos[:, None, :], axis=-1)
+        iu = np.triu_indices(N, 1)
+        assert (d[:, iu[0], iu[1]] >= gap[:, iu[0], iu[1]]).all()                         # starts clear of each other
+        dg = np.linalg.norm(goal[:, :, None] - goal[:, None, :], axis=-1)
+        assert (dg[:, iu[0], iu[1]] >= gap[:, iu[0], iu[1]]).all()                        # goals clear of each other
+        rob_gap = rad + 0.3 + 0.2
+        assert (np.linalg.norm(pos - np.array([0.0, -4.0]), axis=-1) >= rob_gap).all()    # clear of the robot's start
+        if rule == "circle_crossing":
+            assert np.array_equal(goal, -pos)                                             # antipodal goals
+            r = np.linalg.norm(pos, axis=-1)
+            assert (np.abs(r - 4.0) <= 0.5 * np.sqrt(2) * vp + 1e-9).all()                 # on the circle +- noise
+            ang = np.arctan2(pos[..., 1], pos[..., 0])
+            hist, _ = np.histogram(ang, bins=8, range=(-np.pi, np.pi))
+            assert hist.min() > 0.6 * hist.mean()                                         # all directions populated
+            assert (np.linalg.norm(pos - np.array([0.0, 4.0]), axis=-1) >= rob_gap).all() # and of its goal
+        else:
+            assert (np.abs(pos[..., 0]) <= 5.0).all() and (np.abs(pos[..., 1]) <= 5.0).all()
+            assert (np.sign(pos[..., 0]) == -np.sign(goal[..., 0])).all()                 # cross to the other side
+            assert 0.4 < (pos[..., 0] > 0).mean() < 0.6
+
+
+def test_vec_explorer_with_device_scenarios():
+    """k training episodes from device-generated cases: the rollout machinery (in-kernel restart from the device
+    pool, per-episode records) runs end to end and is reproducible."""
+    from modelcrowdnav_amd.rollout import VecExplorer
+    E, N, k = 64, 5, 200
+    outs = []
+    for _ in range(2):
+        env = H.make_vec_env(E, N)
+        env.track_human_times = False; env.export_human_actions = False
+        ex = VecExplorer(env, env.robot, gamma=0.9, policy=object())
+        outs.append((ex.run_k_episodes(k, "train", action_fn=_goal_seeking, device_scenarios=11), ex.last_records))
+    assert outs[0][0] == outs[1][0] and outs[0][1]["returns"] == outs[1][1]["returns"]
+    assert len(outs[0][1]["returns"]) == k and len(set(outs[0][1]["infos"])) > 1
+    assert env.case_counter["train"] == k % env.case_size["train"]

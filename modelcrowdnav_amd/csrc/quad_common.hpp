@@ -101,42 +101,6 @@ __device__ __forceinline__ bool lp3_candidate(const float4 (&L)[4], int no, floa
     return fail == m;
 }
 
-// orca_line_merged (orca_static.hpp) as one straight-line block: the cut-off-circle and the leg projections are both
-// evaluated and the result selected.  Same operations on the selected side, so the same bits.
-__device__ __forceinline__ float4 orca_line_select(float px, float py, float vx, float vy, float radius, float4 o,
-                                                   float orad, float inv_th, float inv_ts)
-{
-    const float rpx = o.x - px, rpy = o.y - py;
-    const float rvx = vx - o.z, rvy = vy - o.w;
-    const float dist_sq = dot2(rpx, rpy, rpx, rpy);
-    const float cr = radius + orad;
-    const float cr_sq = cr * cr;
-    const bool apart = dist_sq > cr_sq;
-    const float inv = apart ? inv_th : inv_ts;          // collision case uses 1/timeStep
-    const float wx = rvx - inv * rpx, wy = rvy - inv * rpy;
-    const float wl_sq = dot2(wx, wy, wx, wy);
-    const float dp1 = dot2(wx, wy, rpx, rpy);
-    const bool circle = !apart | ((dp1 < 0.0f) & (dp1 * dp1 > cr_sq * wl_sq));
-    // cut-off circle
-    const float wl = sqrtf(wl_sq);
-    const float iw = 1.0f / wl;
-    const float uwx = wx * iw, uwy = wy * iw;
-    const float sc = cr * inv - wl;
-    const float cux = sc * uwx, cuy = sc * uwy;
-    // legs
-    const float leg = sqrtf(dist_sq - cr_sq);
-    const float id = 1.0f / dist_sq;
-    const bool left = det2(rpx, rpy, wx, wy) > 0.0f;
-    const float lx = (rpx * leg - rpy * cr) * id, ly = (rpx * cr + rpy * leg) * id;
-    const float rx = -((rpx * leg + rpy * cr) * id), ry = -((-rpx * cr + rpy * leg) * id);
-    const float gx = left ? lx : rx, gy = left ? ly : ry;
-    const float dp2 = dot2(rvx, rvy, gx, gy);
-    const float lux = dp2 * gx - rvx, luy = dp2 * gy - rvy;
-    const float dx = circle ? uwy : gx, dy = circle ? -uwx : gy;
-    const float ux = circle ? cux : lux, uy = circle ? cuy : luy;
-    return make_float4(vx + 0.5f * ux, vy + 0.5f * uy, dx, dy);
-}
-
 // ORCA velocity of the human owning this quad.  Lane k holds candidate neighbour k: `o` = its (px, py, vx, vy) in
 // float32, `crd` its radius, `cand_valid` whether the slot is populated.  The result is identical on the four
 // lanes of the quad (layout: lane = 4 * human + k).

@@ -172,11 +172,15 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
                 const double vx = vel.x - eff.x, vy = vel.y - eff.y;
                 cd = p2s_origin(px, py, px + vx * dt, py + vy * dt) - rad - rrad;
             }
-            int hh;
+            int hh = 0;
             {
+                // the exact test needs a float64 sqrt; it is skipped for the whole wavefront unless some counted
+                // pair is within 1e-6 of touching (a conservative screen: further apart, the exact test is false)
                 const double dx = pos.x - cpos.x, dy = pos.y - cpos.y;
                 const bool counted = (c.count_hh != 0) & cand_h & (j > h);
-                hh = (counted & ((sqrt(dx * dx + dy * dy) - rad - crd) < 0)) ? 1 : 0;
+                const double s2 = dx * dx + dy * dy, reach = rad + crd + 1e-6;
+                if (__any(counted & (s2 < reach * reach)))
+                    hh = (counted & ((sqrt(s2) - rad - crd) < 0)) ? 1 : 0;
             }
             hh += __builtin_amdgcn_update_dpp(0, hh, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
             hh += __builtin_amdgcn_update_dpp(0, hh, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
@@ -201,7 +205,13 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
                 endx = rpos.x + act.x * dt; endy = rpos.y + act.y * dt;
                 nrvx = act.x; nrvy = act.y;
             }
-            const bool reaching = norm2(endx - rgoal.x, endy - rgoal.y) < rrad;
+            // same screen for the goal test: the exact norm (one fma + float64 sqrt) only when some robot of the
+            // wavefront ends within 1e-6 of its goal disc
+            bool reaching = false;
+            {
+                const double gx = endx - rgoal.x, gy = endy - rgoal.y, near = rrad + 1e-6;
+                if (__any(gx * gx + gy * gy < near * near)) reaching = norm2(gx, gy) < rrad;
+            }
             double rew; int inf;
             if (gtime >= k_timeout_at)          { rew = 0; dn = 1; inf = MCN_INFO_TIMEOUT; }
             else if (dmin < 0)                  { rew = k_collision; dn = 1; inf = MCN_INFO_COLLISION; }

@@ -112,17 +112,17 @@ __device__ __forceinline__ bool lp1_s(const float4 (&L)[NL], float radius, float
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < NO; ++i) {
+        // select form: the lanes that reach this point run every step anyway; a parallel line's quotient is
+        // computed and discarded instead of being branched around
         const float4 li = L[i];
         const float den = det2(ln.z, ln.w, li.z, li.w);
         const float num = det2(li.z, li.w, ln.x - li.x, ln.y - li.y);
-        if (fabsf(den) <= kRvoEps) {
-            if (num < 0.0f) ok = false;
-        } else {
-            const float t = num / den;
-            if (den >= 0.0f) tr = fminf(tr, t);
-            else             tl = fmaxf(tl, t);
-            if (tl > tr) ok = false;
-        }
+        const float t = num / den;
+        const bool par = fabsf(den) <= kRvoEps;
+        const float ntr = fminf(tr, t), ntl = fmaxf(tl, t);
+        tr = (!par & (den >= 0.0f)) ? ntr : tr;
+        tl = (!par & !(den >= 0.0f)) ? ntl : tl;
+        ok = ok & !(par & (num < 0.0f)) & !(!par & (tl > tr));
     }
     // a failed lane keeps computing garbage that is discarded: once ok is false it stays false,
     // and the reference returns at the first failure without touching the result

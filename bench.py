@@ -428,6 +428,12 @@ def main():
             sweep.append(roofline_entry(Es, N, g_ms, {"mode": "pairwise + reward + integrate (given velocities, "
                                                               "ModelCrowdSim.step)",
                                                        "env_steps_per_sec": round(Es / (g_ms * 1e-3), 1)}, given=True))
+            env_s.detach_rollout()          # SURVEY 8(d) "pairwise kernel alone": no Explorer record, no restart
+            n_ms, _ = time_kernel_events(env_s, a_s, 50, given_v=gv)
+            sweep.append(roofline_entry(Es, N, n_ms, {"mode": "pairwise + reward + integrate, no Explorer record / "
+                                                              "auto-restart (plain ModelCrowdSim.step)",
+                                                       "env_steps_per_sec": round(Es / (n_ms * 1e-3), 1)}, given=True))
+            sweep[-1]["traffic"] = None
             del gv
             del env_s, a_s
         result["roofline_sweep"] = sweep

@@ -103,7 +103,7 @@ typedef struct mcn_roll_rec {
     double  ep_return;         /* running discounted sum */
     int32_t ep_steps;          /* steps taken in the running episode */
     int32_t fin_count;         /* episodes finished so far */
-    int32_t next_case;         /* pool index used at the next reset; advanced by case_stride mod pool_size */
+    int32_t next_case;         /* pool index used at the next reset, in [0, pool_size); advanced by case_stride mod pool_size */
     int32_t danger_count;      /* steps whose info was Danger ("too close", explorer.py:88-90) */
     double  danger_dist_sum;   /* sum of their min_dist */
 } mcn_roll_rec;
@@ -123,7 +123,7 @@ typedef struct mcn_rollout {
     const double *pool_hrad, *pool_hvpref;               /* [P*N]    */
     const double *pool_hvel;                             /* [P*N][2] or NULL (zeros) */
     int32_t pool_size;
-    int32_t case_stride;       /* pool resets need `state` (its next_case field) */
+    int32_t case_stride;       /* in [0, pool_size); pool resets need `state` (its next_case field) */
     double  robot_start[2], robot_goal[2], robot_theta0;  /* crowd_sim.py:284 */
 } mcn_rollout;
 

@@ -1,6 +1,7 @@
 // env_common.hpp -- float64 helpers shared by the env-step kernels (reference operation order, no contraction).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "../../include/mcn.h"
 
 namespace mcn {
 
@@ -20,6 +21,17 @@ __device__ __forceinline__ double p2s_origin(double x1, double y1, double x2, do
     if (u > 1) u = 1; else if (u < 0) u = 0;
     const double x = x1 + u * px, y = y1 + u * py;
     return norm2(x - 0.0, y - 0.0);
+}
+
+// One env's step record as two stores (16 + 8 bytes): assigning the struct member-wise makes the compiler emit
+// separate byte / short / dword stores for done, info, padding and hh_count.
+__device__ __forceinline__ void store_step_rec(mcn_step_rec *dst, double reward, double dmin, int done, int info, int hh)
+{
+    double *d = reinterpret_cast<double *>(dst);
+    const unsigned long long tail = (unsigned long long)(unsigned)(done & 0xff) | ((unsigned long long)(unsigned)(info & 0xff) << 8) |
+                                    ((unsigned long long)(unsigned)hh << 32);      // little-endian layout of mcn_step_rec
+    reinterpret_cast<double2 *>(d)[0] = make_double2(reward, dmin);
+    reinterpret_cast<unsigned long long *>(d)[2] = tail;
 }
 
 // Python's float % for a positive divisor

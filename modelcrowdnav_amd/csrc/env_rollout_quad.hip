@@ -129,7 +129,8 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
     const double k_theta0 = in_vgpr(ro.robot_theta0);
     const bool has_theta = p.st.rtheta != nullptr;
     double2 act_next = *act_ptr;
-    mcn_step_rec o_last = {0, 0, 0, 0, 0, 0};
+    double o_rew = 0, o_dmin = 0;             // the step record of the latest step (stored once, after the loop)
+    int o_dn = 0, o_inf = 0, o_hh = 0;
     double hax = 0, hay = 0;
 
     for (int t = 0; t < T; ++t) {
@@ -218,8 +219,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
             else if (reaching)                  { rew = k_success; dn = 1; inf = MCN_INFO_REACHGOAL; }
             else if (dmin < k_discomfort)       { rew = (dmin - k_discomfort) * k_factor * dt; dn = 0; inf = MCN_INFO_DANGER; }
             else                                { rew = 0; dn = 0; inf = MCN_INFO_NOTHING; }
-            o_last.reward = rew; o_last.dmin = dmin; o_last.done = (uint8_t)dn; o_last.info = (uint8_t)inf;
-            o_last.hh_count = hh_sum;
+            o_rew = rew; o_dmin = dmin; o_dn = dn; o_inf = inf; o_hh = hh_sum;
             t_new = gtime + dt;
 
             // ---- Explorer accounting (explorer.py:88-99,124): every lane of the env updates its copy of the
@@ -242,7 +242,8 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
                 rs.ep_return = dn ? 0.0 : ret;
                 rs.ep_steps = dn ? 0 : rs.ep_steps + 1;
                 if (do_reset) {
-                    const int nc = (rs.next_case + k_stride) % k_pool;
+                    int nc = rs.next_case + k_stride;            // both < pool_size (validated on the host)
+                    nc = nc >= k_pool ? nc - k_pool : nc;
                     rs.next_case = dn ? nc : rs.next_case;
                 }
             }
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
         if (do_reset) reinterpret_cast<double2 *>(p.st.rgoal)[e] = rgoal;
         if (p.st.rtheta) p.st.rtheta[e] = rtheta;
         p.st.gtime[e] = gtime;
-        p.out.rec[e] = o_last;
+        store_step_rec(p.out.rec + e, o_rew, o_dmin, o_dn, o_inf, o_hh);
         if (has_state) ro.state[e] = rs;
     }
 }

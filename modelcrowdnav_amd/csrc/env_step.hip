@@ -254,9 +254,7 @@ void env_step_kernel(const StepParams p)
         else if (reaching)                  { rew = c.success_reward; dn = 1; inf = MCN_INFO_REACHGOAL; }
         else if (dmin < c.discomfort_dist)  { rew = (dmin - c.discomfort_dist) * c.discomfort_penalty_factor * dt; dn = 0; inf = MCN_INFO_DANGER; }
         else                                { rew = 0; dn = 0; inf = MCN_INFO_NOTHING; }
-        mcn_step_rec o;
-        o.reward = rew; o.dmin = dmin; o.done = (uint8_t)dn; o.info = (uint8_t)inf; o.reserved = 0; o.hh_count = hh_sum;
-        p.out.rec[e] = o;                                // one 24-byte store
+        store_step_rec(p.out.rec + e, rew, dmin, dn, inf, hh_sum);   // 16 + 8 bytes
     }
     if (active && p.out.human_act)
         reinterpret_cast<double2 *>(p.out.human_act)[a] = make_double2(hax, hay);
@@ -310,7 +308,10 @@ void env_step_kernel(const StepParams p)
                     if (keep && r.fin_time)   r.fin_time[rec] = (inf == MCN_INFO_TIMEOUT) ? c.time_limit : t_new;
                     if (keep && r.fin_info)   r.fin_info[rec] = (uint8_t)inf;
                     rs.fin_count = k + 1; rs.ep_return = 0; rs.ep_steps = 0;
-                    if (do_reset) rs.next_case = (next_case + r.case_stride) % r.pool_size;
+                    if (do_reset) {                          // both < pool_size (validated on the host): no division
+                        const int nc = next_case + r.case_stride;
+                        rs.next_case = nc >= r.pool_size ? nc - r.pool_size : nc;
+                    }
                 } else {
                     rs.ep_return = ret; rs.ep_steps += 1;
                 }

@@ -153,9 +153,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void env_step_quad_kernel(const S
     else if (dmin < c.discomfort_dist)  { rew = (dmin - c.discomfort_dist) * c.discomfort_penalty_factor * dt; dn = 0; inf = MCN_INFO_DANGER; }
     else                                { rew = 0; dn = 0; inf = MCN_INFO_NOTHING; }
     if (lead) {
-        mcn_step_rec o;
-        o.reward = rew; o.dmin = dmin; o.done = (uint8_t)dn; o.info = (uint8_t)inf; o.reserved = 0; o.hh_count = hh_sum;
-        p.out.rec[e] = o;                                // one 24-byte store
+        store_step_rec(p.out.rec + e, rew, dmin, dn, inf, hh_sum);   // 16 + 8 bytes
     }
     }   // do_pair
     if (SPLIT) {
@@ -211,7 +209,10 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void env_step_quad_kernel(const S
                     if (keep && ro.fin_time)   ro.fin_time[rec] = (inf == MCN_INFO_TIMEOUT) ? c.time_limit : t_new;
                     if (keep && ro.fin_info)   ro.fin_info[rec] = (uint8_t)inf;
                     rs.fin_count = k + 1; rs.ep_return = 0; rs.ep_steps = 0;
-                    if (do_reset) rs.next_case = (next_case + ro.case_stride) % ro.pool_size;
+                    if (do_reset) {
+                        const int nc = next_case + ro.case_stride;
+                        rs.next_case = nc >= ro.pool_size ? nc - ro.pool_size : nc;
+                    }
                 } else {
                     rs.ep_return = ret; rs.ep_steps += 1;
                 }

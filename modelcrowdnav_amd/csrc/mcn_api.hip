@@ -46,6 +46,7 @@ static int fill_step_params(mcn::StepParams &p, const mcn_env_cfg *cfg, const mc
         if (roll->state && (!roll->disc_table || roll->disc_len <= 0 || roll->fin_slots < 1)) return MCN_EINVAL;
         if (roll->pool_hpos && !roll->state) return MCN_EINVAL;
         if (roll->pool_hpos && (!roll->pool_hgoal || !roll->pool_hrad || !roll->pool_hvpref || roll->pool_size <= 0)) return MCN_EINVAL;
+        if (roll->pool_hpos && (roll->case_stride < 0 || roll->case_stride >= roll->pool_size)) return MCN_EINVAL;
     }
     memset(&p, 0, sizeof(p));
     p.cfg = *cfg; p.st = *st; p.out = *out;

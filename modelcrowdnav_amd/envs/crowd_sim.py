@@ -349,7 +349,7 @@ class VecCrowdSim(object):
             r.pool_hpos, r.pool_hgoal = _hip.ptr(t["pool_hpos"]), _hip.ptr(t["pool_hgoal"])
             r.pool_hrad, r.pool_hvpref = _hip.ptr(t["pool_hrad"]), _hip.ptr(t["pool_hvpref"])
             r.pool_hvel = _hip.ptr(t["pool_hvel"])
-            r.pool_size, r.case_stride = P, int(case_stride)
+            r.pool_size, r.case_stride = P, int(case_stride) % P
             rr = self.spec().robot_row()
             r.robot_start[0], r.robot_start[1] = rr[S.PX], rr[S.PY]
             r.robot_goal[0], r.robot_goal[1] = rr[S.GX], rr[S.GY]

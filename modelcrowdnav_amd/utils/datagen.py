@@ -13,12 +13,15 @@ infos stay on the device and the value targets are computed by the same batched 
 (`rollout.value_targets`).  The host-side random draws (episode choice, cut length) are made with Python's `random`
 in the reference's order, so with the same seed and a greedy policy the samples are the reference's samples.
 
-Not carried over this round (raise NotImplementedError): `replace_robot` (robot takes over a human's track),
-`view_distance` / `view_human` filters (they make the human count ragged per env), episodes whose human count
-changes over time, `render_path`.
+`replace_robot` (the robot takes over one recorded pedestrian's start and goal, datagen.py:262-317) is decided per
+sample on the host with the reference's arithmetic and draws; the chosen pedestrian's column is dropped on the device.
+
+Not carried over this round (raise NotImplementedError): `view_distance` / `view_human` filters (they make the
+human count ragged per env), episodes whose human count changes over time, `render_path`.
 """
 import copy
 import logging
+import math
 import random
 
 import numpy as np
@@ -77,16 +80,20 @@ class VecDataGen(object):
         explorer.py:116-121) -> device tensors: obs [n_epi, T_max, N, 5] float64, length [n_epi]."""
         raw = self._raw_list()
         starts = self.get_episode_start_index()
-        epis = []
+        epis, ses = [], []
         for s in starts:
             rows = []
+            se = None
             for data in raw[s:]:
                 ob = _ob_rows(data[0])
                 if 0 < max_human < len(ob):
                     ob = ob[:max_human]
                 rows.append(ob)
+                if len(data) == 5:                       # has start_ends (misc.py:88): the last visited row's copy
+                    se = data[4][:max_human] if max_human > 0 else data[4]
                 if data[2]:
                     break
+            ses.append(None if se is None else np.asarray(se, np.float64).reshape(-1, 4))
             n = {r.shape[0] for r in rows}
             if len(n) != 1:
                 raise NotImplementedError("episode starting at raw_memory[%d] changes its human count (%s)" % (s, sorted(n)))
@@ -100,11 +107,42 @@ class VecDataGen(object):
             obs[i, :e.shape[0]] = e
         dev = self.env.device
         self._epi = dict(starts=starts, slot={s: i for i, s in enumerate(starts)},
-                         obs=torch.from_numpy(obs).to(dev), length=[e.shape[0] for e in epis], max_human=max_human)
+                         obs=torch.from_numpy(obs).to(dev), length=[e.shape[0] for e in epis], max_human=max_human,
+                         start_ends=ses, first=[e[0] for e in epis])
         return self._epi
 
     # ------------------------------------------------------------------ sample list (host RNG, reference order)
-    def _draw_samples(self, num_sample, min_end, static_end, add_sim, random_epi, test_case):
+    def _pick_robot(self, start_end, first_obs, random_robot):
+        """datagen.py:262-313: which recorded pedestrian the robot replaces, and the robot's padded start / goal.
+        Returns (index, (px, py, gx, gy)) or (None, None) when no pedestrian qualifies.  Same arithmetic, same
+        `random` draws (one randrange per attempt when random_robot)."""
+        distances = [np.linalg.norm([p[2] - p[0], p[3] - p[1]]) for p in start_end]
+        avr_dis = np.average(distances)
+        limit = self.env.time_limit * self.robot.v_pref
+        possible = [i for i in range(len(distances)) if limit > distances[i] > avr_dis]
+        if random_robot is False:                 # longest admissible paths first (note: [-0:] keeps the whole list)
+            order = sorted(list(enumerate(distances)), key=lambda x: x[1])[-len(possible):][::-1]
+            possible = [c[0] for c in order]
+        radius = float(self.robot.radius)
+        min_dis = 0
+        px = py = gx = gy = set_robot = None
+        while min_dis < radius * 4:               # the robot must not start on top of a pedestrian
+            if len(possible) == 0:
+                return None, None
+            set_robot = possible.pop(0) if random_robot is False else possible.pop(random.randrange(len(possible)))
+            others = [first_obs[i] for i in range(len(first_obs)) if i != set_robot]
+            px, py, gx, gy = [start_end[set_robot][i] for i in range(4)]
+            mv = [gx - px, gy - py]
+            pad_x = 2 * math.sin(mv[0] / np.linalg.norm(mv))
+            pad_y = 2 * math.sin(mv[1] / np.linalg.norm(mv))
+            px, py, gx, gy = px - pad_x, py - pad_y, gx + pad_x, gy + pad_y
+            init_dis = [np.linalg.norm([px - h[0], py - h[1]]) for h in others]
+            if len(init_dis) > 0:
+                min_dis = min(init_dis)
+        return set_robot, (float(px), float(py), float(gx), float(gy))
+
+    def _draw_samples(self, num_sample, min_end, static_end, add_sim, random_epi, test_case, replace_robot=False,
+                      random_robot=True):
         ep = self._epi
         indexes = ep["starts"]
         picks = []
@@ -123,6 +161,14 @@ class VecDataGen(object):
                 if i not in ep["slot"]:
                     raise NotImplementedError("test_case must be the raw_memory index of an episode start")
             L = ep["length"][ep["slot"][i]]
+            robot = (None, None)
+            if replace_robot:                                # :262-317, before the length test as in get_real_state
+                se = ep["start_ends"][ep["slot"][i]]
+                if se is None:
+                    raise ValueError("replace_robot needs raw_memory rows with start_ends (misc.py:85-89)")
+                robot = self._pick_robot(se.tolist(), ep["first"][ep["slot"][i]].tolist(), random_robot)
+                if robot[0] is None:                         # `raw_states == []` -> continue (:409-410)
+                    continue
             if L <= min_end:                                 # :412-413
                 continue
             length = L
@@ -130,7 +176,7 @@ class VecDataGen(object):
                 length = random.randrange(min_end, L)
                 if static_end > 0:
                     length = static_end
-            picks.append((ep["slot"][i], min(length, L)))
+            picks.append((ep["slot"][i], min(length, L)) + (robot if replace_robot else ()))
         return picks
 
     # ------------------------------------------------------------------ the batched loop
@@ -142,8 +188,8 @@ class VecDataGen(object):
         """Same arguments and return value as datagen.py:379-518.  `sgan_genfile` (the text file that seeds the
         SGAN world model's history in the reference, :421-430) is honoured by seeding the HBM history ring of a
         VecSGANWorld with the last `min_end` real frames of every sample; its value is otherwise unused."""
-        if replace_robot or view_distance > 0 or view_human > 0 or render_path is not None:
-            raise NotImplementedError("replace_robot / view filters / render_path are not carried over")
+        if view_distance > 0 or view_human > 0 or render_path is not None:
+            raise NotImplementedError("view filters / render_path are not carried over")
         env, pol = self.env, self.policy
         if self._epi is None or self._epi["max_human"] != max_human:
             self.load_real_episodes(max_human)
@@ -151,7 +197,10 @@ class VecDataGen(object):
         E, dev = env.num_envs, env.device
         N = ep["obs"].shape[2]
         pol.set_phase(phase)
-        picks = self._draw_samples(num_sample, min_end, static_end, add_sim, random_epi, test_case)
+        picks = self._draw_samples(num_sample, min_end, static_end, add_sim, random_epi, test_case, replace_robot,
+                                   random_robot)
+        if replace_robot:
+            N -= 1                                        # the replaced pedestrian's column is dropped
         horizon = int(round(env.time_limit / env.time_step)) + 2
         v_pref, dt = float(self.robot.v_pref), float(env.time_step)
         gbar = pow(self.gamma, dt * v_pref)
@@ -167,8 +216,17 @@ class VecDataGen(object):
             length = torch.tensor([p[1] for p in pad], device=dev)
             obs = ep["obs"][slot]                                         # [E,T,N,5]
             T_rec = obs.shape[1]
+            rpos = rgoal = None
+            if replace_robot:
+                # drop the replaced pedestrian's column (:315-317); the robot starts / ends at the padded track ends
+                drop = torch.tensor([p[2] for p in pad], device=dev).view(E, 1)
+                cols = torch.arange(N, device=dev).view(1, N).expand(E, N)
+                cols = cols + (cols >= drop).long()
+                obs = torch.gather(obs, 2, cols.view(E, 1, N, 1).expand(E, T_rec, N, 5))
+                info_t = torch.tensor([p[3] for p in pad], dtype=torch.float64, device=dev)
+                rpos, rgoal = info_t[:, 0:2].contiguous(), info_t[:, 2:4].contiguous()
             env.set_current_state(obs[:, 0, :, 0:2].contiguous(), obs[:, 0, :, 2:4].contiguous(),
-                                  torch.full((E, N), human_radius, dtype=torch.float64, device=dev))
+                                  torch.full((E, N), human_radius, dtype=torch.float64, device=dev), rpos, rgoal)
             hist0 = None
             if add_sim and sgan_genfile is not None and hasattr(sim, "reset_history"):
                 # the reference writes raw_states[-min_end:] of the cut episode (:423-430); frames before the

@@ -17,10 +17,14 @@ from tests import helpers as H  # noqa: E402
 
 RUNS = [("il_freeze", dict(imitation_learning=True, add_sim=False, random_epi=True), 3, 12),
         ("rl_imagine", dict(imitation_learning=False, add_sim=True, random_epi=False), 4, 10),
-        ("il_static", dict(imitation_learning=True, add_sim=True, random_epi=True, static_end=9), 5, 9)]
+        ("il_static", dict(imitation_learning=True, add_sim=True, random_epi=True, static_end=9), 5, 9),
+        ("il_replace_rand", dict(imitation_learning=True, add_sim=True, random_epi=True, replace_robot=True,
+                                 random_robot=True), 6, 8),
+        ("rl_replace_long", dict(imitation_learning=False, add_sim=False, random_epi=False, replace_robot=True,
+                                 random_robot=False), 7, 7)]
 
 
-def _setup(g, name, E):
+def _setup(g, name, E, n_world=5):
     import torch
     from modelcrowdnav_amd import configs
     from modelcrowdnav_amd.envs import VecModelCrowdSim
@@ -37,7 +41,7 @@ def _setup(g, name, E):
     pol.set_device(dev); pol.set_phase("val"); pol.time_step = 0.25
     env.robot.set_policy(pol)
     pol.set_env(env)
-    world = MlpWorld(5)
+    world = MlpWorld(n_world)
     pref = name + "_world__"
     world.load_state_dict({k[len(pref):].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith(pref)})
     world.eval().to(dev)
@@ -48,8 +52,9 @@ def _setup(g, name, E):
     i = 0
     while "epi%d" % i in g.files:
         e = g["epi%d" % i]
+        start_ends = [[e[0, h, 0], e[0, h, 1], e[-1, h, 0], e[-1, h, 1]] for h in range(e.shape[1])]
         for t in range(e.shape[0]):
-            raw.append((e[t], 0, t == e.shape[0] - 1, None))
+            raw.append((e[t], 0, t == e.shape[0] - 1, None, start_ends))
         i += 1
     dg.raw_memory = raw
     dg.update_target_model(pol.model)
@@ -60,7 +65,7 @@ def _setup(g, name, E):
 @pytest.mark.parametrize("E", [4, 16])
 def test_explore_in_mix_matches_reference(name, kw, seed, num, E, golden_dir):
     g = np.load(os.path.join(golden_dir, "g8_datagen.npz"))
-    dg, memory = _setup(g, name, E)
+    dg, memory = _setup(g, name, E, 4 if kw.get("replace_robot") else 5)
     random.seed(seed)
     out = dg.gen_data_from_explore_in_mix(num, phase="val", min_end=8, returnRate=False, **kw)
     want = g[name + "_out"]
@@ -79,7 +84,7 @@ def test_explore_in_mix_rejects_what_is_not_carried_over(golden_dir):
     g = np.load(os.path.join(golden_dir, "g8_datagen.npz"))
     dg, _ = _setup(g, "il_freeze", 4)
     with pytest.raises(NotImplementedError):
-        dg.gen_data_from_explore_in_mix(2, phase="val", min_end=8, replace_robot=True)
+        dg.gen_data_from_explore_in_mix(2, phase="val", min_end=8, view_distance=3.0)
     with pytest.raises(NotImplementedError):
         dg.gen_data_from_explore_in_mix(2, phase="val", min_end=8, view_human=3)
     assert dg.count() == 7

@@ -180,12 +180,16 @@ def g8_datagen():
             raw.append((ob, 0, t == e.shape[0] - 1, Nothing(), start_ends))
     runs = [("il_freeze", dict(imitation_learning=True, add_sim=False, random_epi=True), 3, 12),
             ("rl_imagine", dict(imitation_learning=False, add_sim=True, random_epi=False), 4, 10),
-            ("il_static", dict(imitation_learning=True, add_sim=True, random_epi=True, static_end=9), 5, 9)]
+            ("il_static", dict(imitation_learning=True, add_sim=True, random_epi=True, static_end=9), 5, 9),
+            ("il_replace_rand", dict(imitation_learning=True, add_sim=True, random_epi=True, replace_robot=True,
+                                     random_robot=True), 6, 8),
+            ("rl_replace_long", dict(imitation_learning=False, add_sim=False, random_epi=False, replace_robot=True,
+                                     random_robot=False), 7, 7)]
     for name, kw, seed, num in runs:
         torch.manual_seed(3)            # default-init SARL weights that happen to drive to the goal: memory gets rows
         env, robot, pol = G.make_env("ModelCrowdSim", robot_policy="sarl", humans_policy="orca", human_num=5)
         torch.manual_seed(100 + seed)
-        world = MlpWorld(5)
+        world = MlpWorld(4 if kw.get("replace_robot") else 5)      # the replaced pedestrian leaves the crowd
         world.eval()
         env.sim_world = world
         env.device = torch.device("cpu")

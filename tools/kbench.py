@@ -43,6 +43,9 @@ def main():
             g = gv if mode.startswith("given") else None
             if mode.endswith("-noroll"):
                 env.detach_rollout()        # no Explorer bookkeeping / auto-reset: fewer per-env streams
+            if mode.endswith("-nopool"):
+                env.detach_rollout()
+                env.attach_rollout(gamma=0.9)   # Explorer record only, no restart from the pool
             for t in range(8):
                 env.step(acts[t], given_v=g)
             torch.cuda.synchronize()

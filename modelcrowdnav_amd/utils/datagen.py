@@ -16,8 +16,12 @@ in the reference's order, so with the same seed and a greedy policy the samples 
 `replace_robot` (the robot takes over one recorded pedestrian's start and goal, datagen.py:262-317) is decided per
 sample on the host with the reference's arithmetic and draws; the chosen pedestrian's column is dropped on the device.
 
-Not carried over this round (raise NotImplementedError): `view_distance` / `view_human` filters (they make the
-human count ragged per env), episodes whose human count changes over time, `render_path`.
+`view_human` (the policy sees, and the memory stores, only the n closest pedestrians, closest first,
+datagen.py:365-377) is a stable sort + gather into a shadow state that the look-ahead kernel and `transform_batch` read.
+
+Not carried over this round (raise NotImplementedError): the `view_distance` filter (it makes the human count ragged
+per env, which the fixed-N look-ahead launch does not take), episodes whose human count changes over time,
+`render_path`.
 """
 import copy
 import logging
@@ -37,6 +41,35 @@ def _ob_rows(ob):
     if len(ob) and hasattr(ob[0], "px"):
         return np.array([[h.px, h.py, h.vx, h.vy, h.radius] for h in ob], np.float64)
     return np.asarray(ob, np.float64).reshape(-1, 5)
+
+
+class _NearestView(object):
+    """What the policy may look at when `view_human` = n: the env's robot plus its n closest pedestrians, closest
+    first (CorrectViewByNHuman, datagen.py:365-377).  Exposes the slice of the VecCrowdSim surface that
+    `predict_batch` / `transform_batch` read."""
+
+    def __init__(self, env, n):
+        self.env, self.n = env, min(int(n), env._alloc_N)
+        self.num_envs, self.device, self.robot, self._alloc_N = env.num_envs, env.device, env.robot, self.n
+        E, dev = env.num_envs, env.device
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float64, device=dev)
+        self.hpos, self.hvel, self.hgoal, self.hrad, self.hvpref = z(E, self.n, 2), z(E, self.n, 2), z(E, self.n, 2), z(E, self.n), z(E, self.n)
+        for k in ("rpos", "rvel", "rgoal", "rrad", "rvpref", "rtheta", "gtime"):
+            setattr(self, k, getattr(env, k))
+        self.human_times = z(E, self.n)
+        self._st = _hip.EnvState(*[_hip.ptr(t) for t in (self.hpos, self.hvel, self.hgoal, self.hrad, self.hvpref,
+                                                         self.rpos, self.rvel, self.rgoal, self.rrad, self.rvpref,
+                                                         self.rtheta, self.gtime, self.human_times)])
+
+    def refresh(self):
+        env = self.env
+        d = env.hpos - env.rpos.unsqueeze(1)                       # norm([rpx - h.px, rpy - h.py]) per pedestrian
+        dist = torch.sqrt(torch.addcmul(d[..., 0] * d[..., 0], d[..., 1], d[..., 1]))
+        idx = torch.argsort(dist, dim=1, stable=True)[:, :self.n]
+        i2 = idx.unsqueeze(2).expand(-1, -1, 2)
+        self.hpos.copy_(torch.gather(env.hpos, 1, i2)); self.hvel.copy_(torch.gather(env.hvel, 1, i2))
+        self.hrad.copy_(torch.gather(env.hrad, 1, idx))
+        return self
 
 
 class VecDataGen(object):
@@ -188,8 +221,8 @@ class VecDataGen(object):
         """Same arguments and return value as datagen.py:379-518.  `sgan_genfile` (the text file that seeds the
         SGAN world model's history in the reference, :421-430) is honoured by seeding the HBM history ring of a
         VecSGANWorld with the last `min_end` real frames of every sample; its value is otherwise unused."""
-        if view_distance > 0 or view_human > 0 or render_path is not None:
-            raise NotImplementedError("view filters / render_path are not carried over")
+        if view_distance > 0 or render_path is not None:
+            raise NotImplementedError("view_distance / render_path are not carried over")
         env, pol = self.env, self.policy
         if self._epi is None or self._epi["max_human"] != max_human:
             self.load_real_episodes(max_human)
@@ -237,12 +270,14 @@ class VecDataGen(object):
                 sim.reset_history(hist0)
             states, rewards, dones, infos = [], [], [], []
             alive = torch.ones(E, dtype=torch.bool, device=dev)
+            view = _NearestView(env, view_human) if (view_human > 0 and not stay) else None
             for i in range(horizon):
-                states.append(pol.transform_batch(env))
+                seen = view.refresh() if view is not None else env      # what the policy sees and the memory stores
+                states.append(pol.transform_batch(seen))
                 if stay:
                     act = torch.zeros(E, 2, dtype=torch.float64, device=dev)
                 else:
-                    act, _ = pol.predict_batch(env)
+                    act, _ = pol.predict_batch(seen)
                     eps = float(getattr(pol, "epsilon", 0) or 0)
                     if phase == "train" and eps > 0:            # multi_human_rl.py:28-30, one draw per env
                         table = pol._bufs["table"]

@@ -21,7 +21,8 @@ RUNS = [("il_freeze", dict(imitation_learning=True, add_sim=False, random_epi=Tr
         ("il_replace_rand", dict(imitation_learning=True, add_sim=True, random_epi=True, replace_robot=True,
                                  random_robot=True), 6, 8),
         ("rl_replace_long", dict(imitation_learning=False, add_sim=False, random_epi=False, replace_robot=True,
-                                 random_robot=False), 7, 7)]
+                                 random_robot=False), 7, 7),
+        ("il_view3", dict(imitation_learning=True, add_sim=False, random_epi=True, view_human=3), 8, 8)]
 
 
 def _setup(g, name, E, n_world=5):
@@ -85,6 +86,4 @@ def test_explore_in_mix_rejects_what_is_not_carried_over(golden_dir):
     dg, _ = _setup(g, "il_freeze", 4)
     with pytest.raises(NotImplementedError):
         dg.gen_data_from_explore_in_mix(2, phase="val", min_end=8, view_distance=3.0)
-    with pytest.raises(NotImplementedError):
-        dg.gen_data_from_explore_in_mix(2, phase="val", min_end=8, view_human=3)
     assert dg.count() == 7

@@ -11,6 +11,7 @@ in-kernel.  With several ranks, envs are sharded by global env id and the record
 all_gather (dist.gather_records).
 """
 import logging
+import os
 
 import numpy as np
 import torch
@@ -64,6 +65,8 @@ class VecExplorer(object):
         self.memory = memory
         self.target_policy = target_policy       # supplies transform() in imitation learning (explorer.py:163)
         self.target_model = None
+        self.raw_memory = None                   # list / ReplayMemory-like: rows (ob [N,5], reward, done, info code)
+        self.rawob = None                        # list / ReplayMemory-like: (humans [N,4], next velocities [N,2])
 
     def update_target_model(self, target_model):
         import copy
@@ -73,6 +76,34 @@ class VecExplorer(object):
         gbar = pow(self.gamma, self.env.time_step * float(self.robot.v_pref))
         return value_targets(states, rewards, dones, infos, imitation_learning, gbar, self.target_model, self.device)
 
+    def _emit_collected(self, cur, ob, rew, done, info, k, rounds, E_total, update_raw_ob, cache_dir):
+        """Split the recorded [T,E,...] traces at the dones and hand the k episodes out in the reference's order
+        (episode g = round * E + env): raw_memory rows, world-model pairs, SGAN cache files."""
+        T, E = done.shape
+        bounds = []
+        for e in range(E):
+            ends = np.nonzero(done[:, e])[0][:rounds]
+            starts = np.concatenate([[0], ends[:-1] + 1])
+            bounds.append(list(zip(starts.tolist(), ends.tolist())))
+        push = lambda store, item: (store.push if hasattr(store, "push") else store.append)(item)
+        fcount = 0
+        for g in range(k):
+            e, r = g % E_total, g // E_total
+            t0, t1 = bounds[e][r]
+            frames = []
+            for t in range(t0, t1 + 1):
+                if self.raw_memory is not None:
+                    push(self.raw_memory, (ob[t, e].copy(), float(rew[t, e]), bool(done[t, e]), int(info[t, e])))
+                if update_raw_ob and (np.abs(ob[t, e, :, 2:4]) > 1e-3).any():        # someone_is_moving
+                    push(self.rawob, (torch.from_numpy(cur[t, e]).float(), torch.from_numpy(ob[t, e, :, 2:4].copy()).float()))
+                fid = 10 * (t - t0 + 1)
+                frames += [[fid, p, ob[t, e, p, 0], ob[t, e, p, 1]] for p in range(ob.shape[2])]
+            if cache_dir is not None:
+                fcount += 1
+                with open(os.path.join(cache_dir, str(fcount) + ".txt"), "w") as fh:
+                    for fr in frames:
+                        fh.write("%s\t%s\t%s\t%s\n" % (fr[0], fr[1], fr[2], fr[3]))
+
     def _actions(self, step_actions):
         if step_actions is not None:
             return step_actions
@@ -81,7 +112,8 @@ class VecExplorer(object):
 
     def run_k_episodes(self, k, phase, update_memory=False, imitation_learning=False, episode=None,
                        print_failure=False, returnRate=True, returnNav=False, action_fn=None, max_steps=None,
-                       total_envs=None, action_seq=None, device_scenarios=None):
+                       total_envs=None, action_seq=None, device_scenarios=None, stay=False, update_raw_ob=False,
+                       cacheFile=None):
         """Returns what Explorer.run_k_episodes returns (explorer.py:146-151):
         (avg cumulative reward, success rate, collision rate, timeout rate[, avg nav time])
         or counts instead of rates when returnRate is False.  `action_fn(env, t) -> [E,2]` overrides the
@@ -90,7 +122,11 @@ class VecExplorer(object):
         state in registers) instead of one launch per step; not combinable with update_memory.
         `device_scenarios=seed` builds the k scenarios on the device (mcn_scenario_pool: the reference's placement
         rules, counter-based random stream -- for training rollouts that need many distinct cases, not for parity
-        runs) instead of generating them on the host with numpy's MT19937."""
+        runs) instead of generating them on the host with numpy's MT19937.
+        Data collection (explorer.py:60-85,112-121), single process only: `stay` keeps the robot still; with
+        `self.raw_memory` set every step pushes `(ob, reward, done, info)` (ob = [N,5] array of the humans after the
+        step, info = code) in episode order; `update_raw_ob` pushes world-model pairs into `self.rawob`; `cacheFile`
+        (a directory) gets one SGAN text file per episode."""
         env = self.env
         rank, ws = mdist.world()
         E_local = env.num_envs
@@ -138,6 +174,12 @@ class VecExplorer(object):
             raise ValueError("Memory or gamma value is not set!")
         transformer = (self.target_policy if imitation_learning else self.policy) if update_memory else None
         rec_s, rec_r, rec_d, rec_i = [], [], [], []
+        collect = self.raw_memory is not None or update_raw_ob or cacheFile is not None
+        if collect:
+            if ws > 1 or action_seq is not None:
+                raise NotImplementedError("data collection runs in one process, one launch per step")
+            keep_export, env.export_human_actions = env.export_human_actions, True
+            col_cur, col_ob, col_r, col_d, col_i = [], [], [], [], []
         t = 0
         if action_seq is not None:
             if update_memory:
@@ -153,8 +195,20 @@ class VecExplorer(object):
         while t < limit:
             if update_memory:
                 rec_s.append(transformer.transform_batch(env))           # the state the action is chosen in
-            a = action_fn(env, t) if action_fn is not None else self._actions(None)
+            if stay:
+                a = torch.zeros(E_local, 2, dtype=torch.float64, device=env.device)
+            else:
+                a = action_fn(env, t) if action_fn is not None else self._actions(None)
+            if collect:
+                prev_pos = env.hpos.clone()
+                col_cur.append(torch.cat([prev_pos, env.hvel], 2))
             env.step(a)
+            if collect:
+                # the observation the reference's step() returns, also for envs that finished and were restarted
+                # in-kernel: humans moved by the velocity they chose (same two roundings as the kernel's integrate)
+                pos = prev_pos + env.human_act * env.time_step
+                col_ob.append(torch.cat([pos, env.human_act, env.hrad.unsqueeze(2)], 2))
+                col_r.append(env.reward.clone()); col_d.append(env.done.bool()); col_i.append(env.info.clone())
             if update_memory:
                 rec_r.append(env.reward.clone()); rec_d.append(env.done.bool()); rec_i.append(env.info.clone())
             t += 1
@@ -172,6 +226,11 @@ class VecExplorer(object):
             s, v = self._value_targets(torch.stack(rec_s), torch.stack(rec_r), dones & valid, torch.stack(rec_i),
                                        imitation_learning)
             self.memory.push_batch(s, v)
+        if collect:
+            env.export_human_actions = keep_export
+            self._emit_collected(torch.stack(col_cur).cpu().numpy(), torch.stack(col_ob).cpu().numpy(),
+                                 torch.stack(col_r).cpu().numpy(), torch.stack(col_d).cpu().numpy(),
+                                 torch.stack(col_i).cpu().numpy(), k, rounds, E_total, update_raw_ob, cacheFile)
         env.case_counter[phase] = (first + k) % size
         # records in global episode order: episode g = r * E_total + global_env
         rec = mdist.gather_records(bufs["fin_return"].t().contiguous(), bufs["fin_info"].t().contiguous(),

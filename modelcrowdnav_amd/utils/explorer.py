@@ -3,11 +3,13 @@ that run one E = 1 gym env (train.py:120-246, test.py:73-109).  The batched equi
 modelcrowdnav_amd.rollout.VecExplorer; this class exists so `Explorer(env, robot, device, memory, gamma,
 target_policy)` keeps working after `dropin.install()`.
 
-Not reproduced: the SGAN text-cache / raw-observation side channels (`cacheFile`, `raw_memory`,
-`update_raw_ob`, explorer.py:71-85,112-121), which belong to the dataset tooling outside this build's scope.
+The data-collection side channels are kept (explorer.py:60-85,112-121): `raw_memory` rows `(ob, reward, done, info)`
+for DataGen, `rawob` pairs (humans' [px,py,vx,vy], their next velocities) for the world-model trainers, and the
+SGAN text cache (`cacheFile/<n>.txt`, one `frame<TAB>ped<TAB>x<TAB>y` line per pedestrian and step).
 """
 import copy
 import logging
+import os
 
 import torch
 
@@ -17,6 +19,10 @@ from ..envs.utils import info as I
 
 def average(xs):
     return sum(xs) / len(xs) if xs else 0
+
+
+def _push(store, item):
+    (store.push if hasattr(store, "push") else store.append)(item)
 
 
 class Explorer(object):
@@ -39,15 +45,26 @@ class Explorer(object):
         self.robot.policy.set_phase(phase)
         outcome = {"success": [], "collision": [], "timeout": []}       # (episode index, time)
         too_close, min_dist, returns = 0, [], []
+        fcount = 0
         for i in range(k):
             ob = self.env.reset(phase, test_case=test_case)
             done, states, actions, rewards = False, [], [], []
+            cache_frames, frameid = [], 0
             while not done:
                 if stay:
                     action = ActionXY(0, 0) if self.robot.policy.kinematics == "holonomic" else ActionRot(0, 0)
                 else:
                     action = self.robot.act(ob)
+                current_s = [o.getvalue() for o in ob]
                 ob, reward, done, info = self.env.step(action)
+                frameid += 10                                           # explorer.py:75-77
+                for p_id, o in enumerate(ob):
+                    cache_frames.append([frameid, p_id, o.px, o.py])
+                if self.raw_memory is not None:                         # :80-81
+                    _push(self.raw_memory, (ob, reward, done, info))
+                if update_raw_ob and self.someone_is_moving(ob):        # :84-86
+                    next_action = [o.getvalue()[2:] for o in ob][:len(current_s)]
+                    _push(self.rawob, (torch.Tensor(current_s), torch.Tensor(next_action)))
                 states.append(self.robot.policy.last_state)
                 actions.append(action)
                 rewards.append(reward)
@@ -64,6 +81,11 @@ class Explorer(object):
                 raise ValueError("Invalid end signal from environment")
             if update_memory and isinstance(info, (I.ReachGoal, I.Collision)):
                 self.update_memory(states, actions, rewards, imitation_learning)
+            if cacheFile is not None:                                   # :116-121
+                fcount += 1
+                with open(os.path.join(cacheFile, str(fcount) + ".txt"), "w") as fh:
+                    for fr in cache_frames:
+                        fh.write("%s\t%s\t%s\t%s\n" % (fr[0], fr[1], fr[2], fr[3]))
             returns.append(sum([self._discount(t) * r for t, r in enumerate(rewards)]))
 
         success, collision = len(outcome["success"]), len(outcome["collision"])
@@ -87,6 +109,11 @@ class Explorer(object):
         if returnRate:
             return average(returns), success / k, collision / k, timeout_n / k
         return average(returns), success, collision, timeout_n
+
+    @staticmethod
+    def someone_is_moving(ob, min_speed=1e-3):
+        """explorer.py:188-192."""
+        return any(abs(h.vx) > min_speed or abs(h.vy) > min_speed for h in ob)
 
     def update_memory(self, states, actions, rewards, imitation_learning=False):
         """explorer.py:153-186: push (state, value) for every step of one finished episode."""

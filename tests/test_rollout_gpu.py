@@ -390,3 +390,63 @@ def test_vec_explorer_with_device_scenarios():
     assert outs[0][0] == outs[1][0] and outs[0][1]["returns"] == outs[1][1]["returns"]
     assert len(outs[0][1]["returns"]) == k and len(set(outs[0][1]["infos"])) > 1
     assert env.case_counter["train"] == k % env.case_size["train"]
+
+
+@pytest.mark.parametrize("stay", [True, False])
+def test_data_collection_side_channels_match_sequential_explorer(stay, tmp_path):
+    """raw_memory rows, world-model pairs and SGAN cache files (explorer.py:60-85,112-121): the batched VecExplorer
+    (E = 4 envs, k = 10 episodes -> 3 rounds with in-kernel restarts) against the sequential Explorer on the E = 1
+    gym view, episode by episode, byte for byte."""
+    import torch
+    import modelcrowdnav_amd.dropin as dropin
+    dropin.install()
+    import gym
+    from crowd_nav.policy.policy_factory import policy_factory
+    from crowd_nav.utils.explorer import Explorer
+    from crowd_sim.envs.utils.robot import Robot
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.rollout import VecExplorer
+    from modelcrowdnav_amd.utils import realdata as RD
+    device = torch.device("cuda:0")
+    k, E = 10, 4
+    seq_dir, vec_dir = tmp_path / "seq", tmp_path / "vec"
+    seq_dir.mkdir(); vec_dir.mkdir()
+    # ---- sequential
+    env_config = configs.env_config()
+    policy = policy_factory["orca"](); policy.configure(env_config)
+    policy.multiagent_training = True                      # 5 humans in 'val' too (crowd_sim.py:275-281)
+    env = gym.make("CrowdSim-v0"); env.configure(env_config)
+    robot = Robot(env_config, "robot"); robot.set_policy(policy); env.set_robot(robot)
+    policy.set_phase("val"); policy.set_device(device); policy.set_env(env)
+    robot.policy.safety_space = 0
+    ex = Explorer(env, robot, device, None, gamma=0.9)
+    ex.raw_memory, ex.rawob = [], []
+    out = ex.run_k_episodes(k, "val", stay=stay, update_raw_ob=True, cacheFile=str(seq_dir))
+    # ---- batched
+    venv = H.make_vec_env(E, 5)
+    venv.track_human_times = False; venv.export_human_actions = False
+    orca = policy_factory["orca"](); orca.multiagent_training = True; orca.safety_space = 0
+    venv.robot.set_policy(orca)
+    vex = VecExplorer(venv, venv.robot, gamma=0.9, policy=orca)
+    vex.raw_memory, vex.rawob = [], []
+    vout = vex.run_k_episodes(k, "val", stay=stay, update_raw_ob=True, cacheFile=str(vec_dir))
+    assert vout[1:] == out[1:] and abs(vout[0] - out[0]) < 1e-12
+    assert len(vex.raw_memory) == len(ex.raw_memory) and len(vex.rawob) == len(ex.rawob) and len(ex.rawob) > 0
+    for got, want in zip(vex.raw_memory, ex.raw_memory):
+        ob = np.array([[h.px, h.py, h.vx, h.vy, h.radius] for h in want[0]])
+        assert np.array_equal(got[0], ob) and got[1] == want[1] and got[2] == want[2] and got[3] == want[3].code
+    for got, want in zip(vex.rawob, ex.rawob):
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    files = sorted(os.listdir(seq_dir), key=lambda f: int(f.split(".")[0]))
+    assert files == ["%d.txt" % (i + 1) for i in range(k)] and sorted(os.listdir(vec_dir)) == sorted(files)
+    for f in files:
+        assert open(vec_dir / f).read() == open(seq_dir / f).read(), f
+    # the cache is what the SGAN side reads back (sgan/sdata/trajectories.py:39-50)
+    rows = RD.read_sgan_cache(str(vec_dir / "1.txt"))
+    assert rows.shape[1] == 4 and rows[0, 0] == 10.0 and set(rows[:, 1]) == {0.0, 1.0, 2.0, 3.0, 4.0}
+    # and the rows feed the batched DataGen
+    from modelcrowdnav_amd.utils.datagen import VecDataGen
+    import types
+    dg = VecDataGen(None, venv.robot, types.SimpleNamespace(device=device), types.SimpleNamespace(gamma=0.9))
+    dg.raw_memory = vex.raw_memory
+    assert dg.count() == k and dg.load_real_episodes()["obs"].shape[2] == 5

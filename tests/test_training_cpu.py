@@ -4,6 +4,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -125,3 +126,36 @@ def test_world_model_modules_match_reference_parameter_names():
     assert a.state_dict()["mlp3.0.weight"].shape == (150, 54) and a.state_dict()["mlp3.6.weight"].shape == (2, 100)
     out = a(torch.randn(4, 20))
     assert out.shape == (4, 10) and a.attention_weights.shape == (5,)
+
+
+def test_world_model_trainer_early_stopping_and_best_weights(tmp_path):
+    """Trainer_Sim (trainer_sim.py:26-110): fits MlpWorld to a synthetic 'next velocity = damped current velocity'
+    law, returns the best validation loss, restores the best weights and records model.mse."""
+    import random
+    from modelcrowdnav_amd.policy.world_model import MlpWorld
+    from modelcrowdnav_amd.utils.trainer_sim import Trainer_Sim, EarlyStopping
+    torch.manual_seed(0); random.seed(0)
+    N = 3
+    g = torch.Generator().manual_seed(2)
+    pairs = []
+    for _ in range(600):
+        cur = torch.rand(N, 4, generator=g) - 0.5
+        pairs.append((cur, 0.8 * cur[:, 2:4]))
+    pairs.append((torch.zeros(N + 1, 4), torch.zeros(N + 1, 2)))        # odd-sized pair: dropped like collate_fn does
+    model = MlpWorld(N, drop_rate=0.0)
+    path = str(tmp_path / "world.pth")
+    tr = Trainer_Sim(model, pairs, torch.device("cpu"), 64, path)
+    with pytest.raises(ValueError):
+        tr.optimize_epoch(1)
+    tr.set_learning_rate(3e-3)
+    first = tr.optimize_epoch(1, reset=True)
+    best = tr.optimize_epoch(40)
+    assert best < 0.5 * first and abs(model.mse - best) < 1e-12
+    saved = torch.load(path, weights_only=True)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, saved[k])                                  # the best weights are the ones in the model
+    es = EarlyStopping(patience=2)
+    lin = torch.nn.Linear(1, 1)
+    for loss in (1.0, 0.9, 0.95, 0.93):
+        es(loss, lin)
+    assert es.early_stop and es.best_score == -0.9 and es.counter == 2

@@ -1,0 +1,67 @@
+"""GPU: the batched model-based pipeline of INTEGRATION.md section 2 end to end on the synthetic recording:
+ndjson ingest -> world-model training (Trainer_Sim) -> mixed-reality data generation with the robot replacing a
+recorded pedestrian (VecDataGen) -> value-network training (Trainer).  Pins that the pieces compose; each piece has
+its own parity test."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests import helpers as H  # noqa: E402
+
+
+def test_recorded_data_to_value_network(golden_dir, tmp_path):
+    import torch
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.envs import VecModelCrowdSim
+    from modelcrowdnav_amd.policy.sarl import SARL
+    from modelcrowdnav_amd.policy.world_model import MlpWorld, VecTorchWorld
+    from modelcrowdnav_amd.utils import realdata
+    from modelcrowdnav_amd.utils.datagen import VecDataGen
+    from modelcrowdnav_amd.utils.memory import ReplayMemory
+    from modelcrowdnav_amd.utils.trainer import Trainer
+    from modelcrowdnav_amd.utils.trainer_sim import Trainer_Sim
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0); random.seed(0)
+    data = realdata.get_real_data(os.path.join(golden_dir, "g9_scenes.ndjson"), phase="test", stride=1, windows_size=12,
+                                  padding_last="moving", padding_first="stay", cache_dir=str(tmp_path))
+    obs, lengths, ids = data.episode_tensor()
+    n_h = obs.shape[2]
+    # keep whole episodes of the majority pedestrian count
+    keep_ids = set(ids)
+    rows, cur = [], 0
+    for sc in data.scenes:
+        T = sc["obs"].shape[0]
+        if sc["id"] in keep_ids:
+            rows += data.raw_memory()[cur:cur + T]
+        cur += T
+    assert len(rows) == int(lengths.sum()) and os.listdir(tmp_path)
+
+    pairs = [p for p in data.world_pairs() if p[0].shape[0] == n_h]
+    world = MlpWorld(n_h - 1, drop_rate=0.0).to(dev)        # the robot replaces one pedestrian: n_h - 1 remain
+    sub = [(p[0][:n_h - 1], p[1][:n_h - 1]) for p in pairs]
+    wt = Trainer_Sim(world, sub, dev, 32, str(tmp_path / "world.pth"))
+    wt.set_learning_rate(2e-3)
+    l0 = wt.optimize_epoch(1, reset=True)
+    l1 = wt.optimize_epoch(30)
+    assert l1 <= l0 and world.mse == l1
+
+    env = H.make_vec_env(16, n_h - 1, cls=VecModelCrowdSim)
+    pol = SARL(); pol.configure(configs.policy_config()); pol.kinematics = "holonomic"
+    pol.set_device(dev); pol.set_phase("train"); pol.set_epsilon(0.1); pol.time_step = 0.25
+    env.robot.set_policy(pol); pol.set_env(env)
+    env.sim_world = VecTorchWorld(world.eval(), env)
+    memory = ReplayMemory(50000, device=dev)
+    gen = VecDataGen(memory, env.robot, env, pol)
+    gen.raw_memory = rows
+    out = gen.gen_data_from_explore_in_mix(40, phase="train", min_end=4, imitation_learning=True, add_sim=True,
+                                           replace_robot=True, returnRate=False)
+    assert out[1] + out[2] + out[3] == 40
+    assert env._alloc_N == n_h - 1
+    if len(memory):                                       # an untrained robot mostly times out; collisions feed the memory
+        tr = Trainer(pol.get_model(), memory, dev, 50)
+        tr.set_learning_rate(0.01)
+        assert np.isfinite(tr.optimize_batch(5))

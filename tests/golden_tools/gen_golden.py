@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz by importing the real reference in THIS container.
 
-Run from the repo root:   python tools/gen_golden.py [--only g1,g2,...]
+Run from the repo root:   python -m tests.golden_tools.gen_golden [--only g1,g2,...]
 
 Nothing here travels to the GPU box except the arrays it writes.  Fixture families
 (SURVEY.md section 8c):
@@ -14,7 +14,7 @@ Nothing here travels to the GPU box except the arrays it writes.  Fixture famili
   g6_sgan       TrajectoryGenerator.forward        sgan/models.py:501-553, world_model.py:234-268
   g7_episode    hand-driven reset/act/step loops   crowd_nav/utils/explorer.py:54-125
 
-ORCA-human fixtures (g2_step_orca, g7) run the reference's env code with tools/refshim's
+ORCA-human fixtures (g2_step_orca, g7) run the reference's env code with tests/golden_tools/refshim's
 rvo2 stand-in, i.e. THIS repo's C solver: they pin the plumbing around the solver, not the
 solver (ORCA parity vs rvo2 stays unpinned).
 """
@@ -25,9 +25,9 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from tools import refshim  # noqa: E402
+from tests.golden_tools import refshim  # noqa: E402
 
 refshim.install()
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -255,7 +255,7 @@ def main():
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     try:
-        from tools import gen_golden_nets
+        from tests.golden_tools import gen_golden_nets
         FAMILIES.update(gen_golden_nets.FAMILIES)
     except ImportError:
         pass

@@ -1,4 +1,4 @@
-"""Golden fixtures for the learned parts (run through tools/gen_golden.py):
+"""Golden fixtures for the learned parts (run through tests/golden_tools/gen_golden.py):
 
   g5_sarl     CADRL.rotate in/out, SARL ValueNetwork forward with seeded default-init weights,
               MultiHumanRL.predict action_values + chosen action      (cadrl.py:217-252, sarl.py:28-65,
@@ -20,7 +20,7 @@ import os
 import numpy as np
 import torch
 
-from tools import gen_golden as G
+from tests.golden_tools import gen_golden as G
 
 OUT, REF = G.OUT, G.REF
 

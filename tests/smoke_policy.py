@@ -25,7 +25,7 @@ def run():
         hum = np.stack([st.hpx[e], st.hpy[e], st.hvx[e], st.hvy[e], st.hr[e]], 1)
         ref, idx = pyref.sarl_predict(w, row, hum, pol._action_table)
         assert np.abs(values[e].cpu().numpy() - ref).max() < 1e-5
-    gold = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden",
+    gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
                         "g6_sgan.npz")
     if os.path.exists(gold):
         from modelcrowdnav_amd.policy.world_model import generator_from_arrays

@@ -1,6 +1,6 @@
 """GPU: batched DataGen ("explore in mixed reality") against what the REAL reference's
 DataGen.gen_data_from_explore_in_mix produced on the same recorded episodes, seeds and weights
-(tests/golden/g8_datagen.npz, generator: tools/gen_golden_nets.py:g8_datagen; datagen.py:379-543).
+(tests/golden/g8_datagen.npz, generator: tests/golden_tools/gen_golden_nets.py:g8_datagen; datagen.py:379-543).
 
 Tolerances: the value network is float32 on both sides in different summation orders (1e-5 on stored states, which
 are float32 rotations of float64 env state; 2e-4 on value targets, which add up to ~100 discounted rewards or a

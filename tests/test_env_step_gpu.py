@@ -100,7 +100,7 @@ def test_given_velocity_and_linear_modes():
                                          ("g2_step_orca", cport.HUMANS_ORCA),
                                          ("g2_step_orca_visible", cport.HUMANS_ORCA)])
 def test_step_matches_reference_fixtures(name, policy, golden_dir):
-    """HIP path against values recorded from the real reference env (tools/gen_golden.py)."""
+    """HIP path against values recorded from the real reference env (tests/golden_tools/gen_golden.py)."""
     torch = _torch()
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     visible = bool(g["robot_visible"])

@@ -1,5 +1,5 @@
 """CPU: the oracle (C restatement) and the host logic against fixtures recorded from the real
-reference (tools/gen_golden.py).  These pin the oracle before it is trusted as the GPU checker."""
+reference (tests/golden_tools/gen_golden.py).  These pin the oracle before it is trusted as the GPU checker."""
 import os
 
 import numpy as np

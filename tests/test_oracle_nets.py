@@ -1,5 +1,5 @@
 """CPU: pin the torch-fp32 restatements (oracle/pyref.py) against fixtures recorded from the real
-reference's SARL and SGAN code (tools/gen_golden_nets.py)."""
+reference's SARL and SGAN code (tests/golden_tools/gen_golden_nets.py)."""
 import os
 
 import numpy as np

@@ -1,6 +1,6 @@
 """Recorded-data formats against what the REAL reference produced on the same file:
 tests/golden/g9_realdata.npz = crowd_nav/utils/misc.py:GetRealData (with the vendored trajnetplusplustools reader)
-run on tests/golden/g9_scenes.ndjson by tools/gen_golden_nets.py:g9_realdata.  Everything is compared exactly:
+run on tests/golden/g9_scenes.ndjson by tests/golden_tools/gen_golden_nets.py:g9_realdata.  Everything is compared exactly:
 observation values are copies / one multiply of file values, cache files are compared byte for byte."""
 import os
 

@@ -73,6 +73,9 @@ typedef struct mcn_env_state {
     double *rtheta;                            /* [E]      */
     double *gtime;                             /* [E]  CrowdSim.global_time */
     double *human_times;                       /* [E*N] or NULL */
+    const int32_t *hcount;                     /* [E] or NULL: pedestrians the ROBOT'S POLICY sees, 1 <= hcount[e] <= N.
+                                                * mcn_sarl_lookahead ignores slots i >= hcount[e] (attention sum, mean,
+                                                * distance test); the env kernels step all N slots regardless */
 } mcn_env_state;
 
 /* What one env reports per step, as ONE 24-byte record: the kernel issues one store per env instead of five

@@ -33,7 +33,7 @@ class EnvCfg(C.Structure):
 
 class EnvState(C.Structure):
     _fields_ = [(k, _vp) for k in ("hpos", "hvel", "hgoal", "hrad", "hvpref", "rpos", "rvel", "rgoal", "rrad", "rvpref",
-                                   "rtheta", "gtime", "human_times")]
+                                   "rtheta", "gtime", "human_times", "hcount")]
 
 
 class EnvOut(C.Structure):

@@ -62,6 +62,7 @@ struct SarlParams {
     // state (same buffers as mcn_env_state)
     const double *rpos, *rvel, *rgoal, *rrad, *rvpref, *rtheta;   // [E][2] / [E]
     const double *hpos, *hvel, *hrad;                             // [E*N][2] / [E*N]
+    const int32_t *hcount;                                        // [E] or NULL: humans the policy sees
     const double *actions;                                // [A][2]
     float4 *workspace;                                    // [waves][N][T100][64] float4
     double *values;                                       // [E*A]
@@ -90,6 +91,10 @@ __global__ __launch_bounds__(kSarlWaves * 64, 2) void sarl_value_kernel(const Sa
     if (!valid) pair = npairs - 1;
     const int e = (int)(pair / p.A), a = (int)(pair - (long)e * p.A);
     const int N = p.N;
+    // pedestrians this pair's env shows to the policy; the loops below stay N long for the whole workgroup (they
+    // contain the weight-staging barriers) and absent slots are masked out of every reduction
+    int ne = N;
+    if (p.hcount) { ne = p.hcount[e]; ne = ne < 1 ? 1 : (ne > N ? N : ne); }
     const double dt = p.dt;
 
     // ---- robot after the candidate action (cadrl.py:104-129), float64 like the reference ----
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, 2) void sarl_value_kernel(const Sa
         const double hr = p.hrad[ha];
         const double qx = hp.x + hv.x * dt, qy = hp.y + hv.y * dt;      // constant-velocity propagate
         const double d = norm2d(npx - qx, npy - qy) - ra.x - hr;        // multi_human_rl.py:70
-        dmin = fmin(dmin, d);
+        dmin = i < ne ? fmin(dmin, d) : dmin;
         const float hx = (float)qx, hy = (float)qy, hvx = (float)hv.x, hvy = (float)hv.y, hrad = (float)hr;
         const float ox = hx - spx, oy = hy - spy;
         float feat[16];
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, 2) void sarl_value_kernel(const Sa
 #pragma unroll
         for (int t = 0; t < T100; ++t) {
             ws[(i * T100 + t) * 64 + lane] = make_float4(h2[t][0], h2[t][1], h2[t][2], h2[t][3]);
-            gsum[t] += h2[t];
+            if (i < ne) gsum[t] += h2[t];
         }
     }
     // reward ladder of MultiHumanRL.compute_reward with its hard-coded constants
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, 2) void sarl_value_kernel(const Sa
 
     // global state = mean over humans (sarl.py:41); its contribution to attention layer 0 is the same for
     // every human of the pair, so it becomes the accumulator init of that layer
-    const float fn = (float)N;
+    const float fn = (float)ne;
 #pragma unroll
     for (int t = 0; t < T100; ++t)
 #pragma unroll
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, 2) void sarl_value_kernel(const Sa
         dense_staged<T100, T1, false, false, 1>(a2, nullptr, sc, p.f.w_atc, p.f.b_atc, S, lane);
         // score of pair j sits in lane j (q = 0), register 0; broadcast to the pair's four lanes
         const float s = __shfl(sc[0][0], j);
-        const float es = (s != 0.0f) ? expf(s) : 0.0f;          // exp(s) * (s != 0), sarl.py:52
+        const float es = (s != 0.0f && i < ne) ? expf(s) : 0.0f;   // exp(s) * (s != 0), sarl.py:52; absent: 0
         if (p.attention && valid && q == 0) p.attention[pair * N + i] = es;   // normalised by the host view
         denom += es;
         f32x4 m1[T100];
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, 2) void sarl_value_kernel(const Sa
 #pragma unroll
         for (int t = 0; t < T50; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pooled[t][r] += es * m2[t][r];
+            for (int r = 0; r < 4; ++r) pooled[t][r] = i < ne ? pooled[t][r] + es * m2[t][r] : pooled[t][r];
     }
 
     // ---- tail: mlp3 on [self(6), pooled(50)] ----
@@ -293,7 +298,7 @@ int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double
     static_assert(sizeof(SarlFrags) == sizeof(mcn_sarl_net), "fragment tables must mirror the C struct");
     for (size_t k = 0; k < sizeof(mcn_sarl_net) / sizeof(float *); ++k) dst[k] = src[k];
     p.rpos = st->rpos; p.rvel = st->rvel; p.rgoal = st->rgoal; p.rrad = st->rrad; p.rvpref = st->rvpref; p.rtheta = st->rtheta;
-    p.hpos = st->hpos; p.hvel = st->hvel; p.hrad = st->hrad;
+    p.hpos = st->hpos; p.hvel = st->hvel; p.hrad = st->hrad; p.hcount = st->hcount;
     p.actions = actions; p.workspace = reinterpret_cast<float4 *>(workspace);
     p.values = values; p.attention = attention;
     p.E = E; p.N = N; p.A = A; p.kinematics = kinematics; p.dt = dt; p.gamma_pow = gamma_pow;

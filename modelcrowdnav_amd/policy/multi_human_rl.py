@@ -134,16 +134,24 @@ class MultiHumanRL(CADRL):
         return self.joint_state_dim + (self.cell_num ** 2 * self.om_channel_size if self.with_om else 0)
 
     # ------------------------------------------------------------------ batched surface
-    def predict_batch(self, env, want_values=False):
+    def predict_batch(self, env, want_values=False, hcount=None):
         """Greedy look-ahead for all E environments of a VecCrowdSim (phase 'test'/'val').
 
         Returns (actions [E,2] float64 device tensor, best [E] int32; -1 where the robot already
-        stands on its goal and the zero action is returned, multi_human_rl.py:22-23)."""
+        stands on its goal and the zero action is returned, multi_human_rl.py:22-23).
+        hcount ([E] int32 device tensor, optional): env e shows only its first hcount[e] pedestrians to the policy
+        (the reference simply hands `predict` a shorter list, e.g. datagen.py:347-363)."""
         if self.action_space is None:
             self.build_action_space(float(env.robot.v_pref))
         dev = env.device
         self._v_pref = float(env.robot.v_pref)
-        values, best, best_val, _ = self._lookahead(env._st, env.num_envs, env._alloc_N, dev)
+        st = env._st
+        if hcount is not None:
+            if hcount.dtype != torch.int32 or not hcount.is_contiguous() or hcount.numel() != env.num_envs:
+                raise ValueError("hcount must be a contiguous int32 tensor with one entry per env")
+            st = _hip.EnvState.from_buffer_copy(env._st)
+            st.hcount = _hip.ptr(hcount)
+        values, best, best_val, _ = self._lookahead(st, env.num_envs, env._alloc_N, dev)
         table = self._bufs["table"]
         idx = best.clamp(min=0).long()
         actions = table[idx] * (best >= 0).unsqueeze(1).to(table.dtype)

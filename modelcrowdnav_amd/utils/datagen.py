@@ -16,12 +16,13 @@ in the reference's order, so with the same seed and a greedy policy the samples 
 `replace_robot` (the robot takes over one recorded pedestrian's start and goal, datagen.py:262-317) is decided per
 sample on the host with the reference's arithmetic and draws; the chosen pedestrian's column is dropped on the device.
 
-`view_human` (the policy sees, and the memory stores, only the n closest pedestrians, closest first,
-datagen.py:365-377) is a stable sort + gather into a shadow state that the look-ahead kernel and `transform_batch` read.
+`view_human` / `view_distance` (the policy sees only the n closest pedestrians / those within a distance,
+datagen.py:346-377) are a stable sort + gather into a shadow state; a ragged count goes to the look-ahead kernel as
+`mcn_env_state.hcount`.
 
-Not carried over this round (raise NotImplementedError): the `view_distance` filter (it makes the human count ragged
-per env, which the fixed-N look-ahead launch does not take), episodes whose human count changes over time,
-`render_path`.
+Not carried over this round (raise NotImplementedError): `view_distance` together with updateMemory (the stored
+states would be ragged; the reference's own Trainer cannot collate those either), episodes whose human count changes
+over time, `render_path`.
 """
 import copy
 import logging
@@ -43,29 +44,51 @@ def _ob_rows(ob):
     return np.asarray(ob, np.float64).reshape(-1, 5)
 
 
-class _NearestView(object):
-    """What the policy may look at when `view_human` = n: the env's robot plus its n closest pedestrians, closest
-    first (CorrectViewByNHuman, datagen.py:365-377).  Exposes the slice of the VecCrowdSim surface that
-    `predict_batch` / `transform_batch` read."""
+class _PolicyView(object):
+    """What the policy may look at under the view filters of datagen.py:346-377: `view_distance` keeps the
+    pedestrians within that distance of the robot (in their original order; the closest one if none is), `view_human`
+    then keeps the n closest of those, closest first.  The kept pedestrians are gathered to the front of a shadow
+    state and their number goes into `hcount`, which the look-ahead kernel honours (mcn_env_state.hcount).  Exposes the
+    slice of the VecCrowdSim surface that `predict_batch` / `transform_batch` read."""
 
-    def __init__(self, env, n):
-        self.env, self.n = env, min(int(n), env._alloc_N)
-        self.num_envs, self.device, self.robot, self._alloc_N = env.num_envs, env.device, env.robot, self.n
+    def __init__(self, env, n=-1, distance=-1.0):
+        self.env, self.n, self.distance = env, int(n), float(distance)
+        N = env._alloc_N
+        self.width = min(self.n, N) if (self.n > 0 and self.distance <= 0) else N      # fixed count: no masking needed
+        self.num_envs, self.device, self.robot, self._alloc_N = env.num_envs, env.device, env.robot, self.width
         E, dev = env.num_envs, env.device
         z = lambda *shape: torch.zeros(*shape, dtype=torch.float64, device=dev)
-        self.hpos, self.hvel, self.hgoal, self.hrad, self.hvpref = z(E, self.n, 2), z(E, self.n, 2), z(E, self.n, 2), z(E, self.n), z(E, self.n)
+        W = self.width
+        self.hpos, self.hvel, self.hgoal, self.hrad, self.hvpref = z(E, W, 2), z(E, W, 2), z(E, W, 2), z(E, W), z(E, W)
         for k in ("rpos", "rvel", "rgoal", "rrad", "rvpref", "rtheta", "gtime"):
             setattr(self, k, getattr(env, k))
-        self.human_times = z(E, self.n)
+        self.human_times = z(E, W)
+        self.hcount = torch.full((E,), W, dtype=torch.int32, device=dev) if self.distance > 0 else None
         self._st = _hip.EnvState(*[_hip.ptr(t) for t in (self.hpos, self.hvel, self.hgoal, self.hrad, self.hvpref,
                                                          self.rpos, self.rvel, self.rgoal, self.rrad, self.rvpref,
-                                                         self.rtheta, self.gtime, self.human_times)])
+                                                         self.rtheta, self.gtime, self.human_times, self.hcount)])
 
     def refresh(self):
         env = self.env
         d = env.hpos - env.rpos.unsqueeze(1)                       # norm([rpx - h.px, rpy - h.py]) per pedestrian
         dist = torch.sqrt(torch.addcmul(d[..., 0] * d[..., 0], d[..., 1], d[..., 1]))
-        idx = torch.argsort(dist, dim=1, stable=True)[:, :self.n]
+        N = dist.shape[1]
+        if self.distance > 0:
+            valid = dist <= self.distance
+            none = ~valid.any(1)
+            closest = torch.zeros_like(valid).scatter_(1, dist.argmin(1, keepdim=True), True)
+            valid = torch.where(none.unsqueeze(1), closest, valid)
+            count = valid.sum(1)
+            if self.n > 0:                                          # n closest of the visible ones, closest first
+                key = torch.where(valid, dist, torch.full_like(dist, float("inf")))
+                count = count.clamp(max=self.n)
+            else:                                                   # visible ones in their original order
+                key = (~valid).to(dist.dtype)
+            idx = torch.argsort(key, dim=1, stable=True)
+            self.hcount.copy_(count.to(torch.int32))
+        else:
+            idx = torch.argsort(dist, dim=1, stable=True)
+        idx = idx[:, :self.width]
         i2 = idx.unsqueeze(2).expand(-1, -1, 2)
         self.hpos.copy_(torch.gather(env.hpos, 1, i2)); self.hvel.copy_(torch.gather(env.hvel, 1, i2))
         self.hrad.copy_(torch.gather(env.hrad, 1, idx))
@@ -221,8 +244,10 @@ class VecDataGen(object):
         """Same arguments and return value as datagen.py:379-518.  `sgan_genfile` (the text file that seeds the
         SGAN world model's history in the reference, :421-430) is honoured by seeding the HBM history ring of a
         VecSGANWorld with the last `min_end` real frames of every sample; its value is otherwise unused."""
-        if view_distance > 0 or render_path is not None:
-            raise NotImplementedError("view_distance / render_path are not carried over")
+        if render_path is not None:
+            raise NotImplementedError("render_path is not carried over")
+        if view_distance > 0 and updateMemory and not stay:
+            raise NotImplementedError("view_distance with updateMemory would store ragged states")
         env, pol = self.env, self.policy
         if self._epi is None or self._epi["max_human"] != max_human:
             self.load_real_episodes(max_human)
@@ -270,14 +295,14 @@ class VecDataGen(object):
                 sim.reset_history(hist0)
             states, rewards, dones, infos = [], [], [], []
             alive = torch.ones(E, dtype=torch.bool, device=dev)
-            view = _NearestView(env, view_human) if (view_human > 0 and not stay) else None
+            view = _PolicyView(env, view_human, view_distance) if ((view_human > 0 or view_distance > 0) and not stay) else None
             for i in range(horizon):
                 seen = view.refresh() if view is not None else env      # what the policy sees and the memory stores
                 states.append(pol.transform_batch(seen))
                 if stay:
                     act = torch.zeros(E, 2, dtype=torch.float64, device=dev)
                 else:
-                    act, _ = pol.predict_batch(seen)
+                    act, _ = pol.predict_batch(seen, hcount=getattr(seen, "hcount", None))
                     eps = float(getattr(pol, "epsilon", 0) or 0)
                     if phase == "train" and eps > 0:            # multi_human_rl.py:28-30, one draw per env
                         table = pol._bufs["table"]

@@ -185,7 +185,10 @@ def g8_datagen():
                                      random_robot=True), 6, 8),
             ("rl_replace_long", dict(imitation_learning=False, add_sim=False, random_epi=False, replace_robot=True,
                                      random_robot=False), 7, 7),
-            ("il_view3", dict(imitation_learning=True, add_sim=False, random_epi=True, view_human=3), 8, 8)]
+            ("il_view3", dict(imitation_learning=True, add_sim=False, random_epi=True, view_human=3), 8, 8),
+            ("view_dist", dict(add_sim=True, random_epi=True, view_distance=3.0, updateMemory=False), 9, 8),
+            ("view_dist2", dict(add_sim=False, random_epi=False, view_distance=2.5, view_human=2, updateMemory=False),
+             10, 7)]
     for name, kw, seed, num in runs:
         torch.manual_seed(3)            # default-init SARL weights that happen to drive to the goal: memory gets rows
         env, robot, pol = G.make_env("ModelCrowdSim", robot_policy="sarl", humans_policy="orca", human_num=5)

@@ -2,7 +2,8 @@
 DataGen.gen_data_from_explore_in_mix produced on the same recorded episodes, seeds and weights
 (tests/golden/g8_datagen.npz, generator: tests/golden_tools/gen_golden_nets.py:g8_datagen; datagen.py:379-543).
 
-Tolerances: the value network is float32 on both sides in different summation orders (1e-5 on stored states, which
+Tolerances: the value and world networks are float32 on both sides in different summation orders (1e-6 on the mean
+return of samples with imagined steps, exact otherwise; 1e-5 on stored states, which
 are float32 rotations of float64 env state; 2e-4 on value targets, which add up to ~100 discounted rewards or a
 network output); sample outcomes, counts and the sample list are exact."""
 import os
@@ -22,7 +23,9 @@ RUNS = [("il_freeze", dict(imitation_learning=True, add_sim=False, random_epi=Tr
                                  random_robot=True), 6, 8),
         ("rl_replace_long", dict(imitation_learning=False, add_sim=False, random_epi=False, replace_robot=True,
                                  random_robot=False), 7, 7),
-        ("il_view3", dict(imitation_learning=True, add_sim=False, random_epi=True, view_human=3), 8, 8)]
+        ("il_view3", dict(imitation_learning=True, add_sim=False, random_epi=True, view_human=3), 8, 8),
+        ("view_dist", dict(add_sim=True, random_epi=True, view_distance=3.0, updateMemory=False), 9, 8),
+        ("view_dist2", dict(add_sim=False, random_epi=False, view_distance=2.5, view_human=2, updateMemory=False), 10, 7)]
 
 
 def _setup(g, name, E, n_world=5):
@@ -71,10 +74,14 @@ def test_explore_in_mix_matches_reference(name, kw, seed, num, E, golden_dir):
     out = dg.gen_data_from_explore_in_mix(num, phase="val", min_end=8, returnRate=False, **kw)
     want = g[name + "_out"]
     assert tuple(out[1:]) == tuple(int(x) for x in want[1:]), (out, want)      # reach goal / collision / timeout counts
-    assert abs(out[0] - want[0]) < 1e-9
+    # imagined steps come from a float32 world model evaluated on different hardware (positions agree to ~1e-7,
+    # which moves the discomfort penalties by ~1e-8); replay-only samples are exact
+    assert abs(out[0] - want[0]) < (1e-6 if kw.get("add_sim", True) else 1e-9)
     assert dg.counter == int(g[name + "_counter"])
     states, values = g[name + "_states"], g[name + "_values"]
     assert len(memory) == states.shape[0]
+    if states.shape[0] == 0:
+        return
     got_s = memory._states[:len(memory)].cpu().numpy()
     got_v = memory._values[:len(memory), 0].cpu().numpy()
     np.testing.assert_allclose(got_s, states, rtol=0, atol=1e-5)
@@ -85,5 +92,7 @@ def test_explore_in_mix_rejects_what_is_not_carried_over(golden_dir):
     g = np.load(os.path.join(golden_dir, "g8_datagen.npz"))
     dg, _ = _setup(g, "il_freeze", 4)
     with pytest.raises(NotImplementedError):
-        dg.gen_data_from_explore_in_mix(2, phase="val", min_end=8, view_distance=3.0)
+        dg.gen_data_from_explore_in_mix(2, phase="val", min_end=8, view_distance=3.0)      # ragged states + memory
+    with pytest.raises(NotImplementedError):
+        dg.gen_data_from_explore_in_mix(2, phase="val", min_end=8, render_path="/tmp/x")
     assert dg.count() == 7

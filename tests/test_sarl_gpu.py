@@ -134,3 +134,41 @@ def test_unicycle_lookahead_matches_oracle():
         hum = np.stack([st.hpx[e], st.hpy[e], st.hvx[e], st.hvy[e], st.hr[e]], 1)
         ref, idx = pyref.sarl_predict(w, row, hum, table, kinematics="unicycle")
         np.testing.assert_allclose(values[e], ref, rtol=0, atol=TOL)
+
+
+def test_per_env_pedestrian_counts():
+    """mcn_env_state.hcount: env e shows only its first hcount[e] pedestrians to the policy.  Values must equal
+    the reference network evaluated on the shorter list (attention sum, mean and distance test all ignore the
+    absent slots), whatever sits in those slots."""
+    import torch
+    rng = np.random.RandomState(17)
+    E, N = 41, 7
+    pol = _policy(seed=4)
+    env = H.make_vec_env(E, N)
+    st = H.random_state(rng, E, N, randomize=True)
+    H.upload(env, st)
+    counts = rng.randint(1, N + 1, E).astype(np.int32)
+    counts[0], counts[1] = N, 1
+    hc = torch.from_numpy(counts).to(env.device)
+    actions, best, values = pol.predict_batch(env, want_values=True, hcount=hc)
+    values, best = values.cpu().numpy().copy(), best.cpu().numpy().copy()
+    full = pol.predict_batch(env, want_values=True)[2].cpu().numpy()
+    assert np.array_equal(values[0], full[0])                         # hcount == N is the unmasked path
+    w = {k: v.detach().cpu() for k, v in pol.model.state_dict().items()}
+    table = pol._action_table
+    for e in range(0, E, 2):
+        n = int(counts[e])
+        row = [st.rpx[e], st.rpy[e], st.rvx[e], st.rvy[e], st.rr[e], st.rgx[e], st.rgy[e], 1.0, 0.0]
+        hum = np.stack([st.hpx[e], st.hpy[e], st.hvx[e], st.hvy[e], st.hr[e]], 1)[:n]
+        ref, idx = pyref.sarl_predict(w, row, hum, table)
+        np.testing.assert_allclose(values[e], ref, rtol=0, atol=TOL)
+    # garbage in the absent slots must not leak in
+    env.hpos[:, 3:] = 1e6; env.hvel[:, 3:] = -7.0
+    hc3 = torch.full((E,), 3, dtype=torch.int32, device=env.device)
+    v3 = pol.predict_batch(env, want_values=True, hcount=hc3)[2].cpu().numpy()
+    e = 5
+    row = [st.rpx[e], st.rpy[e], st.rvx[e], st.rvy[e], st.rr[e], st.rgx[e], st.rgy[e], 1.0, 0.0]
+    hum = np.stack([st.hpx[e], st.hpy[e], st.hvx[e], st.hvy[e], st.hr[e]], 1)[:3]
+    np.testing.assert_allclose(v3[e], pyref.sarl_predict(w, row, hum, table)[0], rtol=0, atol=TOL)
+    with pytest.raises(ValueError):
+        pol.predict_batch(env, hcount=hc.long())

@@ -20,9 +20,13 @@ sample on the host with the reference's arithmetic and draws; the chosen pedestr
 datagen.py:346-377) are a stable sort + gather into a shadow state; a ragged count goes to the look-ahead kernel as
 `mcn_env_state.hcount`.
 
-Not carried over this round (raise NotImplementedError): `view_distance` together with updateMemory (the stored
-states would be ragged; the reference's own Trainer cannot collate those either), episodes whose human count changes
-over time, `render_path`.
+Recordings whose crowd grows over time (misc.py `padding_first='none'`, datagen.py:457-466) replay with the pedestrians
+that have not entered yet parked far outside the scene and hidden from the policy through `hcount`; when a frame brings
+new pedestrians, all pedestrians of that frame are re-placed at their recorded state, as the reference does.
+
+Not carried over this round (raise NotImplementedError): ragged pedestrian counts (`view_distance`, growing crowds)
+together with updateMemory (the stored states would be ragged; the reference's own Trainer cannot collate those
+either) or with imagination (`add_sim`), `render_path`.
 """
 import copy
 import logging
@@ -45,16 +49,18 @@ def _ob_rows(ob):
 
 
 class _PolicyView(object):
-    """What the policy may look at under the view filters of datagen.py:346-377: `view_distance` keeps the
-    pedestrians within that distance of the robot (in their original order; the closest one if none is), `view_human`
-    then keeps the n closest of those, closest first.  The kept pedestrians are gathered to the front of a shadow
-    state and their number goes into `hcount`, which the look-ahead kernel honours (mcn_env_state.hcount).  Exposes the
-    slice of the VecCrowdSim surface that `predict_batch` / `transform_batch` read."""
+    """What the policy may look at: of the pedestrians present in the env (all N, or the first count[e] when the
+    recording's crowd grows over time), `view_distance` keeps those within that distance of the robot (in their
+    original order; the closest one if none is) and `view_human` then keeps the n closest, closest first
+    (datagen.py:346-377).  The kept pedestrians are gathered to the front of a shadow state and their number goes into
+    `hcount`, which the look-ahead kernel honours (mcn_env_state.hcount).  Exposes the slice of the VecCrowdSim surface
+    that `predict_batch` / `transform_batch` read."""
 
-    def __init__(self, env, n=-1, distance=-1.0):
-        self.env, self.n, self.distance = env, int(n), float(distance)
+    def __init__(self, env, n=-1, distance=-1.0, ragged=False):
+        self.env, self.n, self.distance, self.ragged = env, int(n), float(distance), bool(ragged)
         N = env._alloc_N
-        self.width = min(self.n, N) if (self.n > 0 and self.distance <= 0) else N      # fixed count: no masking needed
+        masked = self.distance > 0 or self.ragged
+        self.width = min(self.n, N) if (self.n > 0 and not masked) else N          # fixed count: no masking needed
         self.num_envs, self.device, self.robot, self._alloc_N = env.num_envs, env.device, env.robot, self.width
         E, dev = env.num_envs, env.device
         z = lambda *shape: torch.zeros(*shape, dtype=torch.float64, device=dev)
@@ -63,29 +69,34 @@ class _PolicyView(object):
         for k in ("rpos", "rvel", "rgoal", "rrad", "rvpref", "rtheta", "gtime"):
             setattr(self, k, getattr(env, k))
         self.human_times = z(E, W)
-        self.hcount = torch.full((E,), W, dtype=torch.int32, device=dev) if self.distance > 0 else None
+        self.hcount = torch.full((E,), W, dtype=torch.int32, device=dev) if masked else None
         self._st = _hip.EnvState(*[_hip.ptr(t) for t in (self.hpos, self.hvel, self.hgoal, self.hrad, self.hvpref,
                                                          self.rpos, self.rvel, self.rgoal, self.rrad, self.rvpref,
                                                          self.rtheta, self.gtime, self.human_times, self.hcount)])
 
-    def refresh(self):
+    def refresh(self, count=None):
         env = self.env
         d = env.hpos - env.rpos.unsqueeze(1)                       # norm([rpx - h.px, rpy - h.py]) per pedestrian
         dist = torch.sqrt(torch.addcmul(d[..., 0] * d[..., 0], d[..., 1], d[..., 1]))
         N = dist.shape[1]
-        if self.distance > 0:
-            valid = dist <= self.distance
-            none = ~valid.any(1)
-            closest = torch.zeros_like(valid).scatter_(1, dist.argmin(1, keepdim=True), True)
-            valid = torch.where(none.unsqueeze(1), closest, valid)
-            count = valid.sum(1)
+        if self.hcount is not None:
+            present = torch.ones_like(dist, dtype=torch.bool) if count is None else \
+                torch.arange(N, device=dist.device).view(1, N) < count.view(-1, 1)
+            valid = present
+            if self.distance > 0:
+                valid = present & (dist <= self.distance)
+                none = ~valid.any(1)
+                masked_d = torch.where(present, dist, torch.full_like(dist, float("inf")))
+                closest = torch.zeros_like(valid).scatter_(1, masked_d.argmin(1, keepdim=True), True)
+                valid = torch.where(none.unsqueeze(1), closest, valid)
+            cnt = valid.sum(1)
             if self.n > 0:                                          # n closest of the visible ones, closest first
                 key = torch.where(valid, dist, torch.full_like(dist, float("inf")))
-                count = count.clamp(max=self.n)
+                cnt = cnt.clamp(max=self.n)
             else:                                                   # visible ones in their original order
                 key = (~valid).to(dist.dtype)
             idx = torch.argsort(key, dim=1, stable=True)
-            self.hcount.copy_(count.to(torch.int32))
+            self.hcount.copy_(cnt.to(torch.int32))
         else:
             idx = torch.argsort(dist, dim=1, stable=True)
         idx = idx[:, :self.width]
@@ -150,21 +161,28 @@ class VecDataGen(object):
                 if data[2]:
                     break
             ses.append(None if se is None else np.asarray(se, np.float64).reshape(-1, 4))
-            n = {r.shape[0] for r in rows}
-            if len(n) != 1:
-                raise NotImplementedError("episode starting at raw_memory[%d] changes its human count (%s)" % (s, sorted(n)))
-            epis.append(np.stack(rows))
-        n = {e.shape[1] for e in epis}
-        if len(n) != 1:
-            raise NotImplementedError("recorded episodes have different human counts: %s" % sorted(n))
-        T = max(e.shape[0] for e in epis)
-        obs = np.zeros((len(epis), T, epis[0].shape[1], 5), np.float64)
-        for i, e in enumerate(epis):
-            obs[i, :e.shape[0]] = e
+            cnt = [r.shape[0] for r in rows]
+            if any(b < a for a, b in zip(cnt, cnt[1:])):
+                raise NotImplementedError("episode starting at raw_memory[%d]: the crowd shrinks (%s)" % (s, cnt))
+            P = max(cnt)
+            full = np.zeros((len(rows), P, 5), np.float64)
+            for t, r in enumerate(rows):                      # pedestrians enter at the end of the list (misc.py:136-158)
+                full[t, :r.shape[0]] = r
+            epis.append((full, np.asarray(cnt, np.int64)))
+        T = max(e[0].shape[0] for e in epis)
+        P = max(e[0].shape[1] for e in epis)
+        obs = np.zeros((len(epis), T, P, 5), np.float64)
+        count = np.zeros((len(epis), T), np.int64)
+        for i, (e, c) in enumerate(epis):
+            obs[i, :e.shape[0], :e.shape[1]] = e
+            count[i, :len(c)] = c
+            count[i, len(c):] = c[-1]
         dev = self.env.device
+        ragged = bool((count != P).any())
         self._epi = dict(starts=starts, slot={s: i for i, s in enumerate(starts)},
-                         obs=torch.from_numpy(obs).to(dev), length=[e.shape[0] for e in epis], max_human=max_human,
-                         start_ends=ses, first=[e[0] for e in epis])
+                         obs=torch.from_numpy(obs).to(dev), length=[e[0].shape[0] for e in epis], max_human=max_human,
+                         start_ends=ses, first=[e[0][0, :e[1][0]] for e in epis],
+                         count=torch.from_numpy(count).to(dev) if ragged else None)
         return self._epi
 
     # ------------------------------------------------------------------ sample list (host RNG, reference order)
@@ -257,6 +275,11 @@ class VecDataGen(object):
         pol.set_phase(phase)
         picks = self._draw_samples(num_sample, min_end, static_end, add_sim, random_epi, test_case, replace_robot,
                                    random_robot)
+        ragged = ep["count"] is not None                  # the recorded crowd grows over time (datagen.py:457-466)
+        if ragged and add_sim:
+            raise NotImplementedError("imagining a crowd whose size changes is not carried over (use add_sim=False)")
+        if ragged and updateMemory and not stay:
+            raise NotImplementedError("a growing crowd with updateMemory would store ragged states")
         if replace_robot:
             N -= 1                                        # the replaced pedestrian's column is dropped
         horizon = int(round(env.time_limit / env.time_step)) + 2
@@ -274,6 +297,7 @@ class VecDataGen(object):
             length = torch.tensor([p[1] for p in pad], device=dev)
             obs = ep["obs"][slot]                                         # [E,T,N,5]
             T_rec = obs.shape[1]
+            cnt_all = ep["count"][slot] if ragged else None               # [E,T] pedestrians present per frame
             rpos = rgoal = None
             if replace_robot:
                 # drop the replaced pedestrian's column (:315-317); the robot starts / ends at the padded track ends
@@ -283,8 +307,22 @@ class VecDataGen(object):
                 obs = torch.gather(obs, 2, cols.view(E, 1, N, 1).expand(E, T_rec, N, 5))
                 info_t = torch.tensor([p[3] for p in pad], dtype=torch.float64, device=dev)
                 rpos, rgoal = info_t[:, 0:2].contiguous(), info_t[:, 2:4].contiguous()
-            env.set_current_state(obs[:, 0, :, 0:2].contiguous(), obs[:, 0, :, 2:4].contiguous(),
-                                  torch.full((E, N), human_radius, dtype=torch.float64, device=dev), rpos, rgoal)
+                if ragged:                                # `ob[:h] + ob[h+1:] if len(ob) > h else ob` (:317)
+                    cnt_all = cnt_all - (cnt_all > drop).long()
+            pos0, vel0 = obs[:, 0, :, 0:2].contiguous(), obs[:, 0, :, 2:4].contiguous()
+            cur_cnt = None
+            if ragged:
+                # pedestrians that have not entered yet wait far outside the scene; the policy never sees them
+                # (hcount) and they cannot come near the robot
+                cur_cnt = cnt_all[:, 0].clone()
+                slots = torch.arange(N, device=dev).view(1, N)
+                parked = torch.stack([1000.0 + 10.0 * slots.expand(E, N).double(),
+                                      torch.full((E, N), 1000.0, dtype=torch.float64, device=dev)], 2)
+                absent0 = slots >= cur_cnt.view(E, 1)
+                pos0 = torch.where(absent0.unsqueeze(2), parked, pos0)
+                vel0 = torch.where(absent0.unsqueeze(2), torch.zeros_like(vel0), vel0)
+            env.set_current_state(pos0, vel0, torch.full((E, N), human_radius, dtype=torch.float64, device=dev),
+                                  rpos, rgoal)
             hist0 = None
             if add_sim and sgan_genfile is not None and hasattr(sim, "reset_history"):
                 # the reference writes raw_states[-min_end:] of the cut episode (:423-430); frames before the
@@ -295,9 +333,10 @@ class VecDataGen(object):
                 sim.reset_history(hist0)
             states, rewards, dones, infos = [], [], [], []
             alive = torch.ones(E, dtype=torch.bool, device=dev)
-            view = _PolicyView(env, view_human, view_distance) if ((view_human > 0 or view_distance > 0) and not stay) else None
+            view = _PolicyView(env, view_human, view_distance, ragged) \
+                if ((view_human > 0 or view_distance > 0 or ragged) and not stay) else None
             for i in range(horizon):
-                seen = view.refresh() if view is not None else env      # what the policy sees and the memory stores
+                seen = view.refresh(cur_cnt) if view is not None else env   # what the policy sees and the memory stores
                 states.append(pol.transform_batch(seen))
                 if stay:
                     act = torch.zeros(E, 2, dtype=torch.float64, device=dev)
@@ -311,6 +350,8 @@ class VecDataGen(object):
                         act = torch.where(explore.unsqueeze(1), table[ridx], act)
                 replay = (i + 1) < length                                        # :452 per env
                 nxt = obs[:, min(i + 1, T_rec - 1), :, 2:4]
+                if ragged:                                 # `[...][:self.env.human_num]`: only who is there moves (:453)
+                    nxt = torch.where((slots < cur_cnt.view(E, 1)).unsqueeze(2), nxt, torch.zeros_like(nxt))
                 if add_sim:
                     if bool((~replay).any()):
                         imagined = sim(env.hpos)
@@ -322,6 +363,17 @@ class VecDataGen(object):
                 else:
                     new_v = torch.where(replay.view(E, 1, 1), nxt, torch.zeros_like(nxt))   # humans stop moving
                 env.step(act, new_v=new_v.contiguous())
+                if ragged:
+                    # "add more human when needed" (:457-466): when the next recorded frame has more pedestrians,
+                    # every pedestrian of that frame is (re)placed at its recorded position and velocity
+                    nxt_cnt = torch.where(replay, cnt_all[:, min(i + 1, T_rec - 1)], cur_cnt)
+                    grow = nxt_cnt > cur_cnt
+                    if bool(grow.any()):
+                        put = (grow.view(E, 1) & (slots < nxt_cnt.view(E, 1))).unsqueeze(2)
+                        frame = obs[:, min(i + 1, T_rec - 1)]
+                        env.hpos.copy_(torch.where(put, frame[..., 0:2], env.hpos))
+                        env.hvel.copy_(torch.where(put, frame[..., 2:4], env.hvel))
+                    cur_cnt = nxt_cnt
                 rewards.append(env.reward.clone()); dones.append(env.done.bool() & alive)
                 infos.append(env.info.clone())
                 alive = alive & ~env.done.bool()

@@ -189,6 +189,23 @@ def g8_datagen():
             ("view_dist", dict(add_sim=True, random_epi=True, view_distance=3.0, updateMemory=False), 9, 8),
             ("view_dist2", dict(add_sim=False, random_epi=False, view_distance=2.5, view_human=2, updateMemory=False),
              10, 7)]
+    # recordings whose crowd grows over time (misc.py padding_first='none'): pedestrian k enters at frame enter[k]
+    rng = np.random.RandomState(23)
+    ragged_raw = []
+    for i, e in enumerate(synthetic_recorded_episodes(seed=29, n_epi=6)):
+        T, P = e.shape[0], e.shape[1]
+        enter = np.sort(np.concatenate([[0, 0], rng.randint(1, T // 2, P - 2)]))
+        count = np.array([(enter <= t).sum() for t in range(T)])
+        rec["repi%d" % i], rec["repi%d_count" % i] = e, count
+        first = [int(enter[h]) for h in range(P)]
+        start_ends = [[e[first[h], h, 0], e[first[h], h, 1], e[-1, h, 0], e[-1, h, 1]] for h in range(P)]
+        for t in range(T):
+            ob = [ObservableState(*e[t, h].tolist()) for h in range(int(count[t]))]
+            ragged_raw.append((ob, 0, t == T - 1, Nothing(), start_ends))
+    runs += [("ragged_eval", dict(add_sim=False, random_epi=False, updateMemory=False), 11, 7),
+             ("ragged_view", dict(add_sim=False, random_epi=True, updateMemory=False, view_distance=3.0, view_human=3), 12, 7),
+             ("ragged_replace", dict(add_sim=False, random_epi=False, updateMemory=False, replace_robot=True,
+                                     random_robot=False), 13, 6)]
     for name, kw, seed, num in runs:
         torch.manual_seed(3)            # default-init SARL weights that happen to drive to the goal: memory gets rows
         env, robot, pol = G.make_env("ModelCrowdSim", robot_policy="sarl", humans_policy="orca", human_num=5)
@@ -201,7 +218,7 @@ def g8_datagen():
         rec.update(_state_dict_arrays(world, name + "_world__"))
         memory = ReplayMemory(100000)
         dg = DataGen(memory, robot, env, pol)
-        dg.raw_memory = raw
+        dg.raw_memory = ragged_raw if name.startswith("ragged") else raw
         dg.update_target_model(pol.model)
         random.seed(seed)
         out = dg.gen_data_from_explore_in_mix(num, phase="val", min_end=8, returnRate=False, **kw)

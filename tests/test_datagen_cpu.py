@@ -57,11 +57,17 @@ def test_sample_list_follows_reference_draw_order():
     assert [p[1] for p in picks] == [9, 9, 9] and [p[0] for p in picks] == [w[0] for w in want[:3]]
 
 
-def test_ragged_recordings_are_rejected():
+def test_growing_crowds_load_and_shrinking_ones_are_rejected():
     raw = _raw([6, 6])
-    raw[2] = (np.zeros((4, 5)), 0, False, None)
+    raw[2] = (np.zeros((4, 5)), 0, False, None)              # 3, 3, 4, 3, ... pedestrians: someone vanished
     with pytest.raises(NotImplementedError):
         _datagen(raw).load_real_episodes()
+    grow = _raw([6, 6])
+    for t in (3, 4, 5):
+        grow[t] = (np.full((5, 5), 7.0), 0, t == 5, None)    # two pedestrians enter at frame 3 of episode 0
+    ep = _datagen(grow).load_real_episodes()
+    assert tuple(ep["obs"].shape) == (2, 6, 5, 5) and ep["count"][0].tolist() == [3, 3, 3, 5, 5, 5]
+    assert ep["count"][1].tolist() == [3] * 6 and float(ep["obs"][0, 0, 4, 0]) == 0.0 and ep["first"][0].shape == (3, 5)
     with pytest.raises(RuntimeError):
         dg = _datagen(_raw([5, 6]))
         dg.load_real_episodes()

@@ -25,7 +25,12 @@ RUNS = [("il_freeze", dict(imitation_learning=True, add_sim=False, random_epi=Tr
                                  random_robot=False), 7, 7),
         ("il_view3", dict(imitation_learning=True, add_sim=False, random_epi=True, view_human=3), 8, 8),
         ("view_dist", dict(add_sim=True, random_epi=True, view_distance=3.0, updateMemory=False), 9, 8),
-        ("view_dist2", dict(add_sim=False, random_epi=False, view_distance=2.5, view_human=2, updateMemory=False), 10, 7)]
+        ("view_dist2", dict(add_sim=False, random_epi=False, view_distance=2.5, view_human=2, updateMemory=False), 10, 7),
+        # recordings whose crowd grows over time (pedestrians enter mid-episode, datagen.py:457-466)
+        ("ragged_eval", dict(add_sim=False, random_epi=False, updateMemory=False), 11, 7),
+        ("ragged_view", dict(add_sim=False, random_epi=True, updateMemory=False, view_distance=3.0, view_human=3), 12, 7),
+        ("ragged_replace", dict(add_sim=False, random_epi=False, updateMemory=False, replace_robot=True,
+                                random_robot=False), 13, 6)]
 
 
 def _setup(g, name, E, n_world=5):
@@ -60,6 +65,15 @@ def _setup(g, name, E, n_world=5):
         for t in range(e.shape[0]):
             raw.append((e[t], 0, t == e.shape[0] - 1, None, start_ends))
         i += 1
+    if name.startswith("ragged"):
+        raw, i = [], 0
+        while "repi%d" % i in g.files:
+            e, count = g["repi%d" % i], g["repi%d_count" % i]
+            first = [int(np.argmax(count > h)) for h in range(e.shape[1])]
+            start_ends = [[e[first[h], h, 0], e[first[h], h, 1], e[-1, h, 0], e[-1, h, 1]] for h in range(e.shape[1])]
+            for t in range(e.shape[0]):
+                raw.append((e[t, :int(count[t])], 0, t == e.shape[0] - 1, None, start_ends))
+            i += 1
     dg.raw_memory = raw
     dg.update_target_model(pol.model)
     return dg, memory
@@ -95,4 +109,9 @@ def test_explore_in_mix_rejects_what_is_not_carried_over(golden_dir):
         dg.gen_data_from_explore_in_mix(2, phase="val", min_end=8, view_distance=3.0)      # ragged states + memory
     with pytest.raises(NotImplementedError):
         dg.gen_data_from_explore_in_mix(2, phase="val", min_end=8, render_path="/tmp/x")
+    rg, _ = _setup(g, "ragged_eval", 4)
+    with pytest.raises(NotImplementedError):
+        rg.gen_data_from_explore_in_mix(2, phase="val", min_end=8, add_sim=True, updateMemory=False)   # imagining a growing crowd
+    with pytest.raises(NotImplementedError):
+        rg.gen_data_from_explore_in_mix(2, phase="val", min_end=8, add_sim=False)                       # ragged states + memory
     assert dg.count() == 7

@@ -51,6 +51,7 @@ class VecSGANWorld(object):
         self._gen = torch.Generator(device="cpu")
         if seed is not None:
             self._gen.manual_seed(int(seed))
+        self.fixed_noise = None      # [E,8] float32 device tensor: used instead of fresh draws (reproducible runs)
 
     def reset_history(self, hist):
         """hist: [E,8,N,2] positions, oldest frame first (datagen.py:423-430 writes the last obs_len frames)."""
@@ -68,7 +69,7 @@ class VecSGANWorld(object):
     def __call__(self, cur_pos, noise=None):
         """cur_pos [E,N,2] float64 -> velocities [E,N,2] float64 (a view reused by the next call)."""
         if noise is None:
-            noise = self.draw_noise()
+            noise = self.fixed_noise if self.fixed_noise is not None else self.draw_noise()
         push = self.oldest
         self.oldest = (self.oldest + 1) & 7
         cur = cur_pos if (cur_pos.dtype == torch.float64 and cur_pos.is_contiguous()) else \

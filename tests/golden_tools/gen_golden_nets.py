@@ -202,7 +202,8 @@ def g8_datagen():
         for t in range(T):
             ob = [ObservableState(*e[t, h].tolist()) for h in range(int(count[t]))]
             ragged_raw.append((ob, 0, t == T - 1, Nothing(), start_ends))
-    runs += [("ragged_eval", dict(add_sim=False, random_epi=False, updateMemory=False), 11, 7),
+    runs += [("il_sgan", dict(imitation_learning=True, add_sim=True, random_epi=True, sgan_world=True), 14, 8),
+             ("ragged_eval", dict(add_sim=False, random_epi=False, updateMemory=False), 11, 7),
              ("ragged_view", dict(add_sim=False, random_epi=True, updateMemory=False, view_distance=3.0, view_human=3), 12, 7),
              ("ragged_replace", dict(add_sim=False, random_epi=False, updateMemory=False, replace_robot=True,
                                      random_robot=False), 13, 6)]
@@ -212,10 +213,31 @@ def g8_datagen():
         torch.manual_seed(100 + seed)
         world = MlpWorld(4 if kw.get("replace_robot") else 5)      # the replaced pedestrian leaves the crowd
         world.eval()
+        kw = dict(kw)
+        cache_dir = None
+        if kw.pop("sgan_world", False):
+            # the shipped pooling SGAN generator as the world model (world_model.py:134-268), fed the generator's own
+            # `user_noise` argument with zeros so that the run does not depend on torch's random stream
+            import tempfile
+            from crowd_nav.policy.world_model import SGANWorld
+
+            class ZeroNoise(torch.nn.Module):
+                def __init__(self, g):
+                    super().__init__()
+                    self.g, self.decoder = g, g.decoder
+
+                def forward(self, obs_traj, obs_traj_rel, seq_start_end):
+                    return self.g(obs_traj, obs_traj_rel, seq_start_end, user_noise=torch.zeros(seq_start_end.shape[0], 8))
+            cache_dir = tempfile.TemporaryDirectory()
+            kw["sgan_genfile"] = os.path.join(cache_dir.name, "generate.txt")
+            world = SGANWorld(kw["sgan_genfile"], torch.device("cpu"), obs_len=8, time_step=0.25,
+                              pretrainPath=os.path.join(REF, "sgan", "models", "sgan-p-models", "zara1_8_model.pt"))
+            world.generator = ZeroNoise(world.generator)
         env.sim_world = world
         env.device = torch.device("cpu")
         rec.update(_state_dict_arrays(pol.model, "w__"))          # same seeded weights in every run
-        rec.update(_state_dict_arrays(world, name + "_world__"))
+        if isinstance(world, MlpWorld):
+            rec.update(_state_dict_arrays(world, name + "_world__"))
         memory = ReplayMemory(100000)
         dg = DataGen(memory, robot, env, pol)
         dg.raw_memory = ragged_raw if name.startswith("ragged") else raw

@@ -26,6 +26,8 @@ RUNS = [("il_freeze", dict(imitation_learning=True, add_sim=False, random_epi=Tr
         ("il_view3", dict(imitation_learning=True, add_sim=False, random_epi=True, view_human=3), 8, 8),
         ("view_dist", dict(add_sim=True, random_epi=True, view_distance=3.0, updateMemory=False), 9, 8),
         ("view_dist2", dict(add_sim=False, random_epi=False, view_distance=2.5, view_human=2, updateMemory=False), 10, 7),
+        # the shipped pooling SGAN generator as the world model, history seeded through sgan_genfile (zero user noise)
+        ("il_sgan", dict(imitation_learning=True, add_sim=True, random_epi=True, sgan_world=True), 14, 8),
         # recordings whose crowd grows over time (pedestrians enter mid-episode, datagen.py:457-466)
         ("ragged_eval", dict(add_sim=False, random_epi=False, updateMemory=False), 11, 7),
         ("ragged_view", dict(add_sim=False, random_epi=True, updateMemory=False, view_distance=3.0, view_human=3), 12, 7),
@@ -83,7 +85,17 @@ def _setup(g, name, E, n_world=5):
 @pytest.mark.parametrize("E", [4, 16])
 def test_explore_in_mix_matches_reference(name, kw, seed, num, E, golden_dir):
     g = np.load(os.path.join(golden_dir, "g8_datagen.npz"))
-    dg, memory = _setup(g, name, E, 4 if kw.get("replace_robot") else 5)
+    kw = dict(kw)
+    sgan = kw.pop("sgan_world", False)
+    dg, memory = _setup(g, "il_freeze" if sgan else name, E, 4 if kw.get("replace_robot") else 5)
+    if sgan:
+        import torch
+        from modelcrowdnav_amd.policy.world_model import VecSGANWorld, generator_from_arrays
+        env = dg.env
+        gen = generator_from_arrays(np.load(os.path.join(golden_dir, "g6_sgan.npz")), "p", env.device)
+        env.sim_world = VecSGANWorld(gen, E, 5, env.device, time_step=env.time_step)
+        env.sim_world.fixed_noise = torch.zeros(E, 8, dtype=torch.float32, device=env.device)
+        kw["sgan_genfile"] = "generate.txt"            # seeds the HBM history ring; no file is written
     random.seed(seed)
     out = dg.gen_data_from_explore_in_mix(num, phase="val", min_end=8, returnRate=False, **kw)
     want = g[name + "_out"]
@@ -98,6 +110,14 @@ def test_explore_in_mix_matches_reference(name, kw, seed, num, E, golden_dir):
         return
     got_s = memory._states[:len(memory)].cpu().numpy()
     got_v = memory._values[:len(memory), 0].cpu().numpy()
+    if sgan:
+        # SGANWorld rounds every history position to 1e-4 (world_model.py:169,192): a float32 prediction that lands
+        # within ~1e-7 of a rounding boundary flips by 1e-4 between CPU torch and the HIP kernel, i.e. 4e-4 in the next
+        # velocity.  Such flips are isolated; everything else agrees to the usual 1e-5.
+        diff = np.abs(got_s - states)
+        assert diff.max() < 2e-3 and (diff > 1e-5).mean() < 0.03, (diff.max(), (diff > 1e-5).mean())
+        np.testing.assert_allclose(got_v, values, rtol=0, atol=2e-3)
+        return
     np.testing.assert_allclose(got_s, states, rtol=0, atol=1e-5)
     np.testing.assert_allclose(got_v, values, rtol=0, atol=2e-4)
 

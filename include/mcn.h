@@ -274,10 +274,13 @@ int64_t mcn_sgan_workspace_bytes(int32_t E, int32_t N);
  * world_model.py:238-240).  `oldest` is the ring slot of the oldest of the 8 frames AFTER that push.
  * noise: [E][8] float (user_noise, sgan/models.py:475); out_vel: [E*N][2] float64 velocities
  * (world_model.py:266-268); out_rel: [E*N][2] float predicted displacement or NULL.
+ * hcount: [E] or NULL -- pedestrians present in scene e (1 <= hcount[e] <= N): the pooling module looks only at
+ * partners k < hcount[e] (a scene of hcount[e] pedestrians in the reference); outputs of slots >= hcount[e] are
+ * meaningless.
  */
 int mcn_sgan_step(const mcn_sgan_net *net, double *hist, int32_t push_slot, int32_t oldest, const double *cur_pos,
-                  const float *noise, void *workspace, double *out_vel, float *out_rel, double time_step,
-                  int32_t E, int32_t N, void *stream);
+                  const float *noise, const int32_t *hcount, void *workspace, double *out_vel, float *out_rel,
+                  double time_step, int32_t E, int32_t N, void *stream);
 
 /* Library self-description (host). */
 const char *mcn_version(void);

@@ -118,7 +118,7 @@ def _load():
     lib.mcn_sarl_lookahead.restype = C.c_int
     lib.mcn_sgan_workspace_bytes.argtypes = [_i, _i]
     lib.mcn_sgan_workspace_bytes.restype = C.c_int64
-    lib.mcn_sgan_step.argtypes = [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _vp]
+    lib.mcn_sgan_step.argtypes = [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _vp]
     lib.mcn_sgan_step.restype = C.c_int
     return lib
 

@@ -19,8 +19,8 @@ int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double
                   double gamma_pow, int kinematics, void *workspace, double *values, int32_t *best, double *best_val,
                   float *attention, int E, int N, hipStream_t stream);
 int launch_sgan(const mcn_sgan_net *net, double *hist, int push_slot, int oldest, const double *cur_pos,
-                const float *noise, void *workspace, double *out_vel, float *out_rel, double time_step, int E, int N,
-                hipStream_t stream);
+                const float *noise, const int32_t *hcount, void *workspace, double *out_vel, float *out_rel,
+                double time_step, int E, int N, hipStream_t stream);
 int launch_orca_batch(const float *self, const float *others, const int32_t *n_other, float *out,
                       int B, int M, float neighbor_dist, int max_neighbors, float time_horizon, float time_step,
                       hipStream_t stream);
@@ -204,8 +204,8 @@ int64_t mcn_sgan_workspace_bytes(int32_t E, int32_t N)
 }
 
 int mcn_sgan_step(const mcn_sgan_net *net, double *hist, int32_t push_slot, int32_t oldest, const double *cur_pos,
-                  const float *noise, void *workspace, double *out_vel, float *out_rel, double time_step,
-                  int32_t E, int32_t N, void *stream)
+                  const float *noise, const int32_t *hcount, void *workspace, double *out_vel, float *out_rel,
+                  double time_step, int32_t E, int32_t N, void *stream)
 {
     if (!net || !hist || !noise || !workspace || !out_vel) return MCN_EINVAL;
     if (E <= 0 || N <= 0 || N > MCN_MAX_HUMANS) return MCN_EINVAL;
@@ -215,8 +215,8 @@ int mcn_sgan_step(const mcn_sgan_net *net, double *hist, int32_t push_slot, int3
         const bool pool_only = (k >= 4 && k < 10);
         if (!fp[k] && !(pool_only && !net->pooling)) return MCN_EINVAL;
     }
-    return mcn::launch_sgan(net, hist, push_slot, oldest, cur_pos, noise, workspace, out_vel, out_rel, time_step,
-                            E, N, (hipStream_t)stream);
+    return mcn::launch_sgan(net, hist, push_slot, oldest, cur_pos, noise, hcount, workspace, out_vel, out_rel,
+                            time_step, E, N, (hipStream_t)stream);
 }
 
 }  // extern "C"

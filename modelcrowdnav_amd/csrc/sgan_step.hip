@@ -39,6 +39,7 @@ struct SganParams {
     double *hist;             // [E][8][N][2] rounded positions (ring)
     const double *cur_pos;    // [E*N][2] frame to push, or NULL
     const float *noise;       // [E][8]
+    const int32_t *hcount;    // [E] or NULL: pedestrians present per scene
     float *henc;              // [E*N][32] encoder final hidden state
     float *last;              // [E*N][4]  last_pos.xy, last_rel.xy (float32)
     double *out_vel;          // [E*N][2]
@@ -158,6 +159,8 @@ __global__ __launch_bounds__(kSganWaves * 64, 2) void sgan_decode_kernel(const S
     f32x4 ctx[2];
     if (p.pooling) {
         f32x4 pool = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int ne = N;                                      // partners in this pedestrian's scene (loop stays N long:
+        if (p.hcount) { ne = p.hcount[e]; ne = ne < 1 ? 1 : (ne > N ? N : ne); }     // it holds the staging barriers)
         for (int k = 0; k < N; ++k) {
             const long other = (long)e * N + k;
             const float4 theirs = reinterpret_cast<const float4 *>(p.last)[other];
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(kSganWaves * 64, 2) void sgan_decode_kernel(const S
             f32x4 o[1];
             dense_staged<32, 1, true, false>(hid, nullptr, o, p.f.w_p2, p.f.b_p2, S, lane);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pool[r] = fmaxf(pool[r], o[0][r]);
+            for (int r = 0; r < 4; ++r) pool[r] = k < ne ? fmaxf(pool[r], o[0][r]) : pool[r];
         }
         f32x4 cin[3] = {hi[0], hi[1], pool};
         f32x4 c1[4];
@@ -208,15 +211,15 @@ __global__ __launch_bounds__(kSganWaves * 64, 2) void sgan_decode_kernel(const S
 }
 
 int launch_sgan(const mcn_sgan_net *net, double *hist, int push_slot, int oldest, const double *cur_pos,
-                const float *noise, void *workspace, double *out_vel, float *out_rel, double time_step, int E, int N,
-                hipStream_t stream)
+                const float *noise, const int32_t *hcount, void *workspace, double *out_vel, float *out_rel,
+                double time_step, int E, int N, hipStream_t stream)
 {
     SganParams p;
     static_assert(sizeof(SganFrags) == 20 * sizeof(void *), "fragment table size");
     const float4 *const *src = reinterpret_cast<const float4 *const *>(net);
     const float4 **dst = reinterpret_cast<const float4 **>(&p.f);
     for (int k = 0; k < 20; ++k) dst[k] = src[k];
-    p.hist = hist; p.cur_pos = cur_pos; p.noise = noise;
+    p.hist = hist; p.cur_pos = cur_pos; p.noise = noise; p.hcount = hcount;
     p.henc = reinterpret_cast<float *>(workspace);
     p.last = p.henc + (size_t)E * N * 32;
     p.out_vel = out_vel; p.out_rel = out_rel;

@@ -66,8 +66,10 @@ class VecSGANWorld(object):
     def draw_noise(self):
         return torch.randn(self.E, 8, generator=self._gen).to(self.device)
 
-    def __call__(self, cur_pos, noise=None):
-        """cur_pos [E,N,2] float64 -> velocities [E,N,2] float64 (a view reused by the next call)."""
+    def __call__(self, cur_pos, noise=None, hcount=None):
+        """cur_pos [E,N,2] float64 -> velocities [E,N,2] float64 (a view reused by the next call).
+        hcount ([E] int32, optional): scene e has only its first hcount[e] pedestrians (the rest of the N slots is
+        ignored by the pooling module and their outputs are meaningless)."""
         if noise is None:
             noise = self.fixed_noise if self.fixed_noise is not None else self.draw_noise()
         push = self.oldest
@@ -75,7 +77,7 @@ class VecSGANWorld(object):
         cur = cur_pos if (cur_pos.dtype == torch.float64 and cur_pos.is_contiguous()) else \
             cur_pos.to(self.device, torch.float64).contiguous()
         sgan_step(self.generator, self.hist, push, self.oldest, cur, noise.float().contiguous(), self.time_step,
-                  out_vel=self.out_vel)
+                  out_vel=self.out_vel, hcount=hcount)
         return self.out_vel
 
 

@@ -152,7 +152,7 @@ class TrajectoryGenerator(nn.Module):
 _WS = {}
 
 
-def sgan_step(gen, hist, push_slot, oldest, cur_pos, noise, time_step, want_rel=False, out_vel=None):
+def sgan_step(gen, hist, push_slot, oldest, cur_pos, noise, time_step, want_rel=False, out_vel=None, hcount=None):
     """Thin wrapper over mcn_sgan_step.  hist [E,8,N,2] f64 (modified in place when cur_pos is given)."""
     E, T, N, _ = hist.shape
     dev = hist.device
@@ -165,7 +165,7 @@ def sgan_step(gen, hist, push_slot, oldest, cur_pos, noise, time_step, want_rel=
         out_vel = torch.empty(E, N, 2, dtype=torch.float64, device=dev)
     rel = torch.empty(E * N, 2, dtype=torch.float32, device=dev) if want_rel else None
     rc = _hip.lib.mcn_sgan_step(C.byref(net), _hip.ptr(hist), int(push_slot), int(oldest), _hip.ptr(cur_pos),
-                                _hip.ptr(noise), _hip.ptr(_WS[key]), _hip.ptr(out_vel), _hip.ptr(rel),
+                                _hip.ptr(noise), _hip.ptr(hcount), _hip.ptr(_WS[key]), _hip.ptr(out_vel), _hip.ptr(rel),
                                 float(time_step), E, N, _hip.stream_ptr(dev))
     _hip.check(rc, "mcn_sgan_step")
     return out_vel, rel

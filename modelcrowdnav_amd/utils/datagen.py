@@ -24,9 +24,11 @@ Recordings whose crowd grows over time (misc.py `padding_first='none'`, datagen.
 that have not entered yet parked far outside the scene and hidden from the policy through `hcount`; when a frame brings
 new pedestrians, all pedestrians of that frame are re-placed at their recorded state, as the reference does.
 
+Imagination (`add_sim`) of such a crowd goes through `mcn_sgan_step`'s per-scene counts (VecSGANWorld).
+
 Not carried over this round (raise NotImplementedError): ragged pedestrian counts (`view_distance`, growing crowds)
 together with updateMemory (the stored states would be ragged; the reference's own Trainer cannot collate those
-either) or with imagination (`add_sim`), `render_path`.
+either) or with a fixed-width world model (MlpWorld), `render_path`.
 """
 import copy
 import logging
@@ -276,8 +278,13 @@ class VecDataGen(object):
         picks = self._draw_samples(num_sample, min_end, static_end, add_sim, random_epi, test_case, replace_robot,
                                    random_robot)
         ragged = ep["count"] is not None                  # the recorded crowd grows over time (datagen.py:457-466)
+        sim_counts = False
         if ragged and add_sim:
-            raise NotImplementedError("imagining a crowd whose size changes is not carried over (use add_sim=False)")
+            import inspect
+            sim_counts = env.sim_world is not None and "hcount" in inspect.signature(env.sim_world.__call__).parameters
+            if not sim_counts:
+                raise NotImplementedError("imagining a crowd whose size changes needs a world model that takes "
+                                          "per-scene counts (VecSGANWorld); MlpWorld has a fixed input width")
         if ragged and updateMemory and not stay:
             raise NotImplementedError("a growing crowd with updateMemory would store ragged states")
         if replace_robot:
@@ -329,7 +336,13 @@ class VecDataGen(object):
                 # episode start repeat its first frame (data_loader pads a short track with its first position)
                 k = torch.arange(-(sim.hist.shape[1]), 0, device=dev).view(1, -1) + length.view(-1, 1)
                 k = torch.maximum(k, (length - min_end).clamp(min=0).view(-1, 1))
-                hist0 = torch.gather(obs[..., 0:2], 1, k.view(E, -1, 1, 1).expand(E, k.shape[1], N, 2))
+                k = k.view(E, -1, 1).expand(E, k.shape[1], N)
+                if ragged:
+                    # a pedestrian that enters inside the window stands at its first recorded position before that
+                    # (SGANWorld.data_loader pads a late track with its first sample, world_model.py:166-178)
+                    enters = (cnt_all.unsqueeze(2) <= slots.view(1, 1, N)).sum(1)            # [E,N] first frame present
+                    k = torch.maximum(k, enters.clamp(max=T_rec - 1).unsqueeze(1))
+                hist0 = torch.gather(obs[..., 0:2], 1, k.unsqueeze(3).expand(E, k.shape[1], N, 2))
                 sim.reset_history(hist0)
             states, rewards, dones, infos = [], [], [], []
             alive = torch.ones(E, dtype=torch.bool, device=dev)
@@ -354,7 +367,10 @@ class VecDataGen(object):
                     nxt = torch.where((slots < cur_cnt.view(E, 1)).unsqueeze(2), nxt, torch.zeros_like(nxt))
                 if add_sim:
                     if bool((~replay).any()):
-                        imagined = sim(env.hpos)
+                        imagined = sim(env.hpos, hcount=cur_cnt.to(torch.int32)) if sim_counts else sim(env.hpos)
+                        if ragged:                         # slots nobody stands in stay parked
+                            imagined = torch.where((slots < cur_cnt.view(E, 1)).unsqueeze(2), imagined,
+                                                   torch.zeros_like(imagined))
                         new_v = torch.where(replay.view(E, 1, 1), nxt, imagined)
                         if hist0 is not None and bool(replay.any()):
                             self._restore_history(sim, hist0, replay)

@@ -206,7 +206,8 @@ def g8_datagen():
              ("ragged_eval", dict(add_sim=False, random_epi=False, updateMemory=False), 11, 7),
              ("ragged_view", dict(add_sim=False, random_epi=True, updateMemory=False, view_distance=3.0, view_human=3), 12, 7),
              ("ragged_replace", dict(add_sim=False, random_epi=False, updateMemory=False, replace_robot=True,
-                                     random_robot=False), 13, 6)]
+                                     random_robot=False), 13, 6),
+             ("ragged_sgan", dict(add_sim=True, random_epi=True, updateMemory=False, sgan_world=True), 15, 7)]
     for name, kw, seed, num in runs:
         torch.manual_seed(3)            # default-init SARL weights that happen to drive to the goal: memory gets rows
         env, robot, pol = G.make_env("ModelCrowdSim", robot_policy="sarl", humans_policy="orca", human_num=5)

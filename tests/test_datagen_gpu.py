@@ -32,7 +32,8 @@ RUNS = [("il_freeze", dict(imitation_learning=True, add_sim=False, random_epi=Tr
         ("ragged_eval", dict(add_sim=False, random_epi=False, updateMemory=False), 11, 7),
         ("ragged_view", dict(add_sim=False, random_epi=True, updateMemory=False, view_distance=3.0, view_human=3), 12, 7),
         ("ragged_replace", dict(add_sim=False, random_epi=False, updateMemory=False, replace_robot=True,
-                                random_robot=False), 13, 6)]
+                                random_robot=False), 13, 6),
+        ("ragged_sgan", dict(add_sim=True, random_epi=True, updateMemory=False, sgan_world=True), 15, 7)]
 
 
 def _setup(g, name, E, n_world=5):
@@ -87,7 +88,8 @@ def test_explore_in_mix_matches_reference(name, kw, seed, num, E, golden_dir):
     g = np.load(os.path.join(golden_dir, "g8_datagen.npz"))
     kw = dict(kw)
     sgan = kw.pop("sgan_world", False)
-    dg, memory = _setup(g, "il_freeze" if sgan else name, E, 4 if kw.get("replace_robot") else 5)
+    dg, memory = _setup(g, ("ragged_eval" if name.startswith("ragged") else "il_freeze") if sgan else name, E,
+                        4 if kw.get("replace_robot") else 5)
     if sgan:
         import torch
         from modelcrowdnav_amd.policy.world_model import VecSGANWorld, generator_from_arrays
@@ -131,7 +133,7 @@ def test_explore_in_mix_rejects_what_is_not_carried_over(golden_dir):
         dg.gen_data_from_explore_in_mix(2, phase="val", min_end=8, render_path="/tmp/x")
     rg, _ = _setup(g, "ragged_eval", 4)
     with pytest.raises(NotImplementedError):
-        rg.gen_data_from_explore_in_mix(2, phase="val", min_end=8, add_sim=True, updateMemory=False)   # imagining a growing crowd
+        rg.gen_data_from_explore_in_mix(2, phase="val", min_end=8, add_sim=True, updateMemory=False)   # MlpWorld: fixed width
     with pytest.raises(NotImplementedError):
         rg.gen_data_from_explore_in_mix(2, phase="val", min_end=8, add_sim=False)                       # ragged states + memory
     assert dg.count() == 7

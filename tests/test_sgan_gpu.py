@@ -59,3 +59,38 @@ def test_vec_world_ring_matches_oracle(tag, E, N, golden_dir):
         pr = pyref.sgan_generator(w, t32, r32, N, torch.from_numpy(noise), tag == "p")
         want = pyref.sgan_velocities(pr, t32[-1], 0.25).reshape(E, N, 2)
         np.testing.assert_allclose(got, want, rtol=0, atol=4 * TOL)       # velocity = displacement / 0.25
+
+
+def test_per_scene_pedestrian_counts(golden_dir):
+    """mcn_sgan_step hcount: scene e has only its first hcount[e] pedestrians.  Their velocities must equal the
+    reference generator run on a scene of exactly that many pedestrians (the pooling module must not look at the
+    unused slots, whatever they hold)."""
+    import torch
+    from modelcrowdnav_amd.policy.world_model import VecSGANWorld
+    g, gen = _gen(golden_dir, "p")
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(77)
+    E, N = 19, 6
+    w = {k: v.detach().cpu() for k, v in gen.state_dict().items()}
+    counts = rng.randint(1, N + 1, E).astype(np.int32)
+    counts[0], counts[1] = N, 1
+    pos = rng.uniform(-4, 4, (E, N, 2)); vel = rng.uniform(-0.8, 0.8, (E, N, 2))
+    for e in range(E):                                   # junk in the unused slots
+        pos[e, counts[e]:] = 1000.0 + rng.uniform(0, 50, (N - counts[e], 2))
+    world = VecSGANWorld(gen, E, N, dev, time_step=0.25)
+    world.init_constant_velocity(torch.from_numpy(pos).to(dev), torch.from_numpy(vel).to(dev))
+    frames = [np.around(pos - vel * 0.25 * k, 4) for k in range(7, -1, -1)]
+    hc = torch.from_numpy(counts).to(dev)
+    for step in range(3):
+        pos = pos + vel * 0.25
+        noise = rng.normal(0, 1, (E, 8)).astype(np.float32)
+        got = world(torch.from_numpy(pos).to(dev), torch.from_numpy(noise).to(dev), hcount=hc).cpu().numpy()
+        frames = frames[1:] + [np.around(pos, 4)]
+        for e in range(0, E, 2):
+            n = int(counts[e])
+            traj = np.stack([f[e, :n] for f in frames], 0)                               # [8, n, 2]
+            rel = np.zeros_like(traj); rel[1:] = traj[1:] - traj[:-1]
+            t32, r32 = torch.from_numpy(traj).float(), torch.from_numpy(rel).float()
+            pr = pyref.sgan_generator(w, t32, r32, n, torch.from_numpy(noise[e:e + 1]), True)
+            want = pyref.sgan_velocities(pr, t32[-1], 0.25).reshape(n, 2)
+            np.testing.assert_allclose(got[e, :n], want, rtol=0, atol=4 * TOL)

@@ -228,6 +228,28 @@ def test_rollout_launch_equals_single_steps(N, visible, with_pool, split, monkey
         assert np.array_equal(sc[k].view(np.uint8), sb[k].view(np.uint8)), k
 
 
+def test_rollout_bench_configuration_equals_single_steps():
+    """The benchmark's own workload (bench.build_env: 4096 envs x 5 humans, 500-case pool, 81-entry action table):
+    250-step mcn_env_rollout launches against one mcn_env_step launch per step, every byte of state and records."""
+    torch = _torch()
+    import bench
+    dev = torch.device("cuda", 0)
+    E, N, T = 4096, 5, 400
+    acts = bench.make_actions(T, E, E, 0, dev)
+    a, _ = bench.build_env(E, N, 0, dev)
+    b, _ = bench.build_env(E, N, 0, dev)
+    a.rollout(acts[:250]); a.rollout(acts[250:])
+    for t in range(T):
+        b.step(acts[t])
+    torch.cuda.synchronize()
+    for k in ("hpos", "hvel", "hgoal", "hrad", "hvpref", "rpos", "rvel", "rgoal", "gtime", "step_rec"):
+        assert np.array_equal(getattr(a, k).cpu().numpy().view(np.uint8), getattr(b, k).cpu().numpy().view(np.uint8)), k
+    for k in ("state", "fin_return", "fin_time", "fin_info"):
+        assert np.array_equal(a.rollout_buffers[k].cpu().numpy().view(np.uint8),
+                              b.rollout_buffers[k].cpu().numpy().view(np.uint8)), k
+    assert int(a.rollout_buffers["fin_count"].sum().item()) > 10000
+
+
 def test_rollout_launch_matches_oracle_trajectory():
     """The fused T-step launch against the C oracle stepped T times (no pool: finished envs keep stepping, which the
     oracle does too)."""

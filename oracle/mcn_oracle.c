@@ -37,7 +37,7 @@
  *     build with -ffp-contract=off.
  *   - numpy.linalg.norm of a 2-vector is sqrt(dot(x,x)); on this image's
  *     numpy/OpenBLAS that dot is sqrt(fma(x1,x1,x0*x0)) (verified against
- *     20 000 random pairs, tools/gen_golden.py re-checks it).  norm2() below
+ *     20 000 random pairs, tests/golden_tools/gen_golden.py re-checks it).  norm2() below
  *     therefore uses an explicit fma().
  *   - ORCA velocities are float32 values widened to double
  *     (rvo2 returns C floats through Cython).

@@ -228,6 +228,29 @@ def test_rollout_launch_equals_single_steps(N, visible, with_pool, split, monkey
         assert np.array_equal(sc[k].view(np.uint8), sb[k].view(np.uint8)), k
 
 
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_rollout_launch_unicycle_robot(split, monkeypatch):
+    """The (v, r) robot (float64 sin / cos on the device, agent.py:110-135) through the fused launch: same code as the
+    single step, so the same bytes; the trig-free holonomic kernel is a separate instantiation."""
+    torch = _torch()
+    E, N, T = 500, 5, 60
+    rng = np.random.RandomState(8)
+    acts = torch.from_numpy(np.stack([rng.uniform(0, 1, (T, E)), rng.uniform(-np.pi / 4, np.pi / 4, (T, E))], -1))
+    monkeypatch.setenv("MCN_ROLLOUT_FUSED", "1")
+    monkeypatch.setenv("MCN_ROLLOUT_SPLIT", split)
+    a = _rollout_env(E, N, False, True, kinematics="unicycle")
+    b = _rollout_env(E, N, False, True, kinematics="unicycle")
+    acts_d = acts.to(a.device)
+    a.rollout(acts_d[:37]); a.rollout(acts_d[37:])
+    for t in range(T):
+        b.step(acts_d[t])
+    torch.cuda.synchronize()
+    sa, sb = _snapshot(a), _snapshot(b)
+    for k in sa:
+        assert np.array_equal(sa[k].view(np.uint8), sb[k].view(np.uint8)), k
+    assert float(a.rtheta.abs().max()) > 0.1 and int(a.rollout_buffers["fin_count"].sum().item()) > 0
+
+
 def test_rollout_bench_configuration_equals_single_steps():
     """The benchmark's own workload (bench.build_env: 4096 envs x 5 humans, 500-case pool, 81-entry action table):
     250-step mcn_env_rollout launches against one mcn_env_step launch per step, every byte of state and records."""

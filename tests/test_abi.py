@@ -65,3 +65,23 @@ def test_bad_arguments_are_rejected_on_host():
     assert rc == _hip.MCN_EINVAL
     rc = _hip.lib.mcn_orca_batch(None, None, None, None, 1, 1, 10.0, 10, 5.0, 0.25, None)
     assert rc == _hip.MCN_EINVAL
+
+
+def test_more_bad_arguments_are_rejected_on_host():
+    """mcn_env_rollout / mcn_scenario_pool / mcn_sgan_step validation (host side, no launch)."""
+    import ctypes as C
+    from modelcrowdnav_amd import _hip
+    cfg, st, out = _hip.EnvCfg(), _hip.EnvState(), _hip.EnvOut()
+    fake = C.c_void_p(0x1000)                     # never dereferenced: validation fails first
+    assert _hip.lib.mcn_env_rollout(cfg, st, fake, 0, out, None, 4, 5, None) == _hip.MCN_EINVAL      # T <= 0
+    assert _hip.lib.mcn_env_rollout(cfg, st, None, 8, out, None, 4, 5, None) == _hip.MCN_EINVAL      # no actions
+    assert _hip.lib.mcn_env_rollout(cfg, st, fake, 8, out, None, 4, 5, None) == _hip.MCN_EINVAL      # empty state
+    sc = _hip.ScenarioCfg(4.0, 10.0, 0.2, 0.3, 1.0, 0.3, (0.0, -4.0), (0.0, 4.0), _hip.RULE_CIRCLE, 0)
+    assert _hip.lib.mcn_scenario_pool(sc, 1, 0, 8, 5, None, fake, fake, fake, None) == _hip.MCN_EINVAL
+    assert _hip.lib.mcn_scenario_pool(sc, 1, 0, 0, 5, fake, fake, fake, fake, None) == _hip.MCN_EINVAL   # P <= 0
+    assert _hip.lib.mcn_scenario_pool(sc, 1, 0, 8, 99, fake, fake, fake, fake, None) == _hip.MCN_EINVAL  # N too large
+    bad = _hip.ScenarioCfg(4.0, 10.0, 0.2, 0.3, 1.0, 0.3, (0.0, -4.0), (0.0, 4.0), 7, 0)
+    assert _hip.lib.mcn_scenario_pool(bad, 1, 0, 8, 5, fake, fake, fake, fake, None) == _hip.MCN_EINVAL  # unknown rule
+    assert _hip.lib.mcn_sgan_step(None, fake, 0, 1, None, fake, None, fake, fake, None, 0.25, 4, 5, None) == _hip.MCN_EINVAL
+    r = _hip.Rollout()
+    assert ctypes.sizeof(_hip.ScenarioCfg) == 10 * 8 + 2 * 4

@@ -8,7 +8,7 @@ drawn uniformly from the 81-entry action table by torch.Generator(seed=0), robot
 scenarios = test cases 1000 + (global_env_id mod 500), auto-reset on done from an HBM-resident
 pool of the same 500 scenarios, Explorer-style discounted returns accumulated in-kernel.
 A "step" is one CrowdSim.step of the whole batch.  The robot's actions are a pre-drawn sequence, so the K
-steps go to the device as ceil(K / 250) mcn_env_rollout launches (env state in registers between the steps
+steps go to the device as ceil(K / 1000) mcn_env_rollout launches (env state in registers between the steps
 of a launch; --steps-per-launch 1 = one mcn_env_step launch per step, also reported as single_step_launch).
 Inputs (states, the [K, E, 2] action tensor) are resident in HBM before the timed region; the launches are
 replayed from one hipGraph.
@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--humans", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--steps-per-launch", type=int, default=250,
+    ap.add_argument("--steps-per-launch", type=int, default=1000,
                     help="env steps handed to one mcn_env_rollout call (the action sequence is known up front); "
                          "1 = one mcn_env_step launch per step")
     ap.add_argument("--sweep", type=str, default="65536,1048576,4194304", help="extra batch sizes for roofline_sweep")

@@ -18,10 +18,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- python3 "$ROOT/tools/kbench.py" \
       --sizes 4096,1048576 --modes orca,given --iters 20 > "$OUT/pmc_$C.log" 2>&1 || { tail -5 "$OUT/pmc_$C.log"; exit 1; }
   rocprofv3 --pmc $C --output-format csv -d "$OUT/pmcr_$C" -o pmc -- python3 "$ROOT/tools/kbench.py" \
-      --rollout 250 --sizes 4096 > "$OUT/pmcr_$C.log" 2>&1 || { tail -5 "$OUT/pmcr_$C.log"; exit 1; }
+      --rollout 1000 --sizes 4096 > "$OUT/pmcr_$C.log" 2>&1 || { tail -5 "$OUT/pmcr_$C.log"; exit 1; }
   echo "pmc $C done"
 done
 cd "$ROOT"
 python3 tools/pmc_summary.py "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$DST/${TAG}_pmc_env_step.json" \
     --envs "env_step_kernel<256=1048576,env_step_kernel<64=4096,quad_kernel<5=4096"
-python3 tools/pmc_summary.py "$OUT/pmcr_FETCH_SIZE" "$OUT/pmcr_WRITE_SIZE" "$DST/${TAG}_pmc_env_rollout.json" --steps-per-launch 250 --envs "quad_kernel<5=4096"
+python3 tools/pmc_summary.py "$OUT/pmcr_FETCH_SIZE" "$OUT/pmcr_WRITE_SIZE" "$DST/${TAG}_pmc_env_rollout.json" --steps-per-launch 1000 --envs "quad_kernel<5=4096"

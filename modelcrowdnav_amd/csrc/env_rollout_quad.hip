@@ -51,6 +51,18 @@ __device__ __forceinline__ V in_vgpr(V v)
     return v;
 }
 
+// Operands of the RARE paths (an episode ends: finished-episode record, restart from the pool) are not kept in
+// registers at all: the rare block re-reads them from the kernel-argument segment (scalar loads, constant cache).
+// The empty asm makes the pointer opaque at that point, so the loads cannot be hoisted out of the step loop and
+// turned back into ~30 long-lived registers (which is what spilled to scratch before).
+typedef const __attribute__((address_space(4))) StepParams *KernargPtr;
+__device__ __forceinline__ KernargPtr kernarg_here()
+{
+    KernargPtr q = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();                      // StepParams is argument 0
+    asm volatile("" : "+s"(q));
+    return q;
+}
+
 template <int NT, int VIS, bool UNI, bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_quad_kernel(const StepParams p, const int T)
 {
@@ -116,17 +128,6 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
     const double *disc_table = in_vgpr(ro.disc_table);
     const int disc_last = in_vgpr(ro.disc_len - 1);
     const int k_stride = in_vgpr(ro.case_stride), k_pool = in_vgpr(ro.pool_size);
-    double *fin_return = in_vgpr(ro.fin_return), *fin_time = in_vgpr(ro.fin_time);
-    uint8_t *fin_info = in_vgpr(ro.fin_info);
-    const int fin_slots = in_vgpr(ro.fin_slots);
-    const long fin_stride = in_vgpr((long)p.E);
-    const double2 *pool_hpos = in_vgpr(reinterpret_cast<const double2 *>(ro.pool_hpos));
-    const double2 *pool_hgoal = in_vgpr(reinterpret_cast<const double2 *>(ro.pool_hgoal));
-    const double2 *pool_hvel = in_vgpr(reinterpret_cast<const double2 *>(ro.pool_hvel));
-    const double *pool_hrad = in_vgpr(ro.pool_hrad), *pool_hvpref = in_vgpr(ro.pool_hvpref);
-    const double2 k_start = make_double2(in_vgpr(ro.robot_start[0]), in_vgpr(ro.robot_start[1]));
-    const double2 k_goal = make_double2(in_vgpr(ro.robot_goal[0]), in_vgpr(ro.robot_goal[1]));
-    const double k_theta0 = in_vgpr(ro.robot_theta0);
     const bool has_theta = p.st.rtheta != nullptr;
     double2 act_next = *act_ptr;
     double o_rew = 0, o_dmin = 0;             // the step record of the latest step (stored once, after the loop)
@@ -232,8 +233,12 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
                 const double ret = rs.ep_return + ep_disc * rew;
                 if (lead && dn) {
                     const int kf = rs.fin_count;
+                    const KernargPtr kp = kernarg_here();
+                    const int fin_slots = kp->roll.fin_slots;
+                    double *fin_return = kp->roll.fin_return, *fin_time = kp->roll.fin_time;
+                    uint8_t *fin_info = kp->roll.fin_info;
                     const bool keep = (fin_slots == 1) || (kf < fin_slots);
-                    const long rec = (long)(fin_slots == 1 ? 0 : kf) * fin_stride + e;
+                    const long rec = (long)(fin_slots == 1 ? 0 : kf) * kp->E + e;
                     if (keep && fin_return) fin_return[rec] = ret;
                     if (keep && fin_time)   fin_time[rec] = (inf == MCN_INFO_TIMEOUT) ? k_time_limit : t_new;
                     if (keep && fin_info)   fin_info[rec] = (uint8_t)inf;
@@ -250,8 +255,10 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
 
             // ---- robot: integrate, or back to the start pose ----
             if (do_reset && dn) {
-                rpos = k_start;
-                rgoal = k_goal;
+                const KernargPtr kp = kernarg_here();
+                const double k_theta0 = kp->roll.robot_theta0;
+                rpos = make_double2(kp->roll.robot_start[0], kp->roll.robot_start[1]);
+                rgoal = make_double2(kp->roll.robot_goal[0], kp->roll.robot_goal[1]);
                 rvel = make_double2(0, 0);
                 if (has_theta) rtheta = k_theta0;
                 gtime = 0;
@@ -281,10 +288,12 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
             if (do_reset && dn) {
                 if (active) {
                     const long pa = (long)case_g * NT + h;
-                    pos = pool_hpos[pa];
-                    goal = pool_hgoal[pa];
-                    rad = pool_hrad[pa];
-                    vpref = pool_hvpref[pa];
+                    const KernargPtr kp = kernarg_here();
+                    const double2 *pool_hvel = reinterpret_cast<const double2 *>(kp->roll.pool_hvel);
+                    pos = reinterpret_cast<const double2 *>(kp->roll.pool_hpos)[pa];
+                    goal = reinterpret_cast<const double2 *>(kp->roll.pool_hgoal)[pa];
+                    rad = kp->roll.pool_hrad[pa];
+                    vpref = kp->roll.pool_hvpref[pa];
                     vel = pool_hvel ? pool_hvel[pa] : make_double2(0, 0);
                 }
                 htime = 0;

@@ -118,7 +118,7 @@ class VecExplorer(object):
         (avg cumulative reward, success rate, collision rate, timeout rate[, avg nav time])
         or counts instead of rates when returnRate is False.  `action_fn(env, t) -> [E,2]` overrides the
         policy (e.g. a random-action baseline).  `action_seq` ([T,E,2] device tensor) is a robot whose actions do
-        not depend on the observation: its steps go to the device 32 at a time through mcn_env_rollout (one launch,
+        not depend on the observation: its steps go to the device 128 at a time through mcn_env_rollout (one launch,
         state in registers) instead of one launch per step; not combinable with update_memory.
         `device_scenarios=seed` builds the k scenarios on the device (mcn_scenario_pool: the reference's placement
         rules, counter-based random stream -- for training rollouts that need many distinct cases, not for parity
@@ -186,7 +186,7 @@ class VecExplorer(object):
                 raise ValueError("action_seq rollouts record no per-step states; use action_fn with update_memory")
             limit = min(limit, int(action_seq.shape[0]))
             while t < limit:
-                n = min(32, limit - t)
+                n = min(128, limit - t)                      # per launch: ~30 us fixed cost vs ~3 us per step
                 env.rollout(action_seq[t:t + n])
                 t += n
                 if int(bufs["fin_count"].min().item()) >= rounds:

@@ -97,17 +97,18 @@ int mcn_env_rollout(const mcn_env_cfg *cfg, const mcn_env_state *st, const doubl
     const int rc = fill_step_params(p, cfg, st, actions, nullptr, out, roll, E, N, 1);
     if (rc != MCN_OK) return rc;
     // One launch with the env state held in registers for all T steps where the quad layout applies and beats T
-    // launches of the throughput kernel: measured cross-over on MI355X at ~32 k envs of 5 humans (fused 15.3 us per
-    // step vs 15.3), i.e. ~10 k env groups; below that the fused launch wins by up to 2.5x.  Two cooperating
-    // wavefronts per env group while the doubled grid still finds idle issue slots (<= 1400 groups).
+    // launches of the throughput kernel: measured cross-over on MI355X at ~45 k envs of 5 humans (19.2 vs 18.6 us per
+    // step at 49 152 envs, 13.9 vs 15.3 at 32 768), i.e. ~14 k env groups; below that the fused launch wins by up to
+    // 2.7x.  Two cooperating wavefronts per env group while the doubled grid still finds idle issue slots (measured:
+    // wins up to 1536 groups = 4608 envs, loses from 1707).
     // MCN_ROLLOUT_FUSED=0/1 and MCN_ROLLOUT_SPLIT=0/1 override (tests, tuning).
     const char *env_fused = getenv("MCN_ROLLOUT_FUSED");
     const char *env_split = getenv("MCN_ROLLOUT_SPLIT");
     const int envs_per_wave = 64 / (4 * N) > 0 ? 64 / (4 * N) : 1;
     const long waves = ((long)E + envs_per_wave - 1) / envs_per_wave;
-    const bool fused = env_fused ? atoi(env_fused) != 0 : waves <= 9000;
+    const bool fused = env_fused ? atoi(env_fused) != 0 : waves <= 14000;
     const int step_split = p.quad_split;              // the single-step kernel's own choice, for the T-launch path
-    p.quad_split = env_split ? atoi(env_split) : (waves <= 1400 ? 1 : 0);
+    p.quad_split = env_split ? atoi(env_split) : (waves <= 1536 ? 1 : 0);
     if (fused && !p.force_generic && mcn::launch_env_rollout_quad(p, T, (hipStream_t)stream))
         return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
     p.quad_split = step_split;

@@ -282,6 +282,28 @@ int mcn_sgan_step(const mcn_sgan_net *net, double *hist, int32_t push_slot, int3
                   const float *noise, const int32_t *hcount, void *workspace, double *out_vel, float *out_rel,
                   double time_step, int32_t E, int32_t N, void *stream);
 
+/*
+ * Dispatch overrides (host, process-wide, not stream-ordered; for tests and tuning).  Every env-step arithmetic
+ * exists in several kernel decompositions with bit-identical results; by default the entry points pick one from
+ * the batch shape.  -1 = automatic.  The MCN_FORCE_GENERIC / MCN_QUAD_MAX_ENVS / MCN_QUAD_SPLIT /
+ * MCN_ROLLOUT_FUSED / MCN_ROLLOUT_SPLIT environment variables give the initial values and are read once, at
+ * the first launch; no entry point calls getenv after that.
+ */
+typedef struct mcn_tuning {
+    int32_t force_generic;   /* 1: run-time-N lane-per-human kernel even where a compile-time-N form exists */
+    int32_t quad_max_envs;   /* mcn_env_step: lanes-per-neighbour ("quad") kernel up to this batch size (0 = never) */
+    int32_t quad_split;      /* quad kernel: ORCA and float64 pairwise work on two cooperating wavefronts (0/1) */
+    int32_t rollout_fused;   /* mcn_env_rollout: one T-step launch (1) or T single-step launches (0) */
+    int32_t rollout_split;   /* fused rollout: two cooperating wavefronts per env group (0/1) */
+    int32_t rollout_octet;   /* reserved for the many-lanes-per-human forms (-1 / 0 / 1) */
+    int32_t diag_noop;       /* DIAGNOSTIC build only (make stamp): env kernels return at entry; MCN_EINVAL otherwise */
+    int32_t reserved;
+} mcn_tuning;
+
+/* NULL restores the initial values.  Returns MCN_EINVAL for out-of-range fields. */
+int mcn_set_tuning(const mcn_tuning *t);
+int mcn_get_tuning(mcn_tuning *t);
+
 /* Library self-description (host). */
 const char *mcn_version(void);
 

@@ -10,7 +10,9 @@ import torch  # noqa: F401  -- FIRST: libmcn_hip.so must bind to the HIP runtime
 #                     otherwise two runtimes coexist and torch streams are meaningless to our launches
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmcn_hip.so")
+# MCN_HIP_LIB: an explicit path to another build of the same library (the diagnostic build of
+# `make -C modelcrowdnav_amd/csrc diag`, used by tools/fixed_cost.py); version() says which build is loaded
+LIB_PATH = os.environ.get("MCN_HIP_LIB") or os.path.join(_HERE, "csrc", "libmcn_hip.so")
 
 MCN_OK, MCN_EINVAL, MCN_ELAUNCH = 0, -1, -2
 MAX_HUMANS, MAX_LINES = 32, 10
@@ -87,6 +89,12 @@ class ScenarioCfg(C.Structure):
 RULE_CIRCLE, RULE_SQUARE = 0, 1
 
 
+class Tuning(C.Structure):
+    """mcn_tuning: dispatch overrides, -1 = automatic."""
+    _fields_ = [(k, _i) for k in ("force_generic", "quad_max_envs", "quad_split", "rollout_fused", "rollout_split",
+                                  "rollout_octet", "diag_noop", "reserved")]
+
+
 class McnError(RuntimeError):
     pass
 
@@ -104,6 +112,10 @@ def _load():
     lib.mcn_env_rollout.argtypes = [C.POINTER(EnvCfg), C.POINTER(EnvState), _vp, _i, C.POINTER(EnvOut),
                                     C.POINTER(Rollout), _i, _i, _vp]
     lib.mcn_env_rollout.restype = C.c_int
+    lib.mcn_set_tuning.argtypes = [C.POINTER(Tuning)]
+    lib.mcn_set_tuning.restype = C.c_int
+    lib.mcn_get_tuning.argtypes = [C.POINTER(Tuning)]
+    lib.mcn_get_tuning.restype = C.c_int
     lib.mcn_scenario_pool.argtypes = [C.POINTER(ScenarioCfg), C.c_uint64, C.c_int64, _i, _i, _vp, _vp, _vp, _vp, _vp]
     lib.mcn_scenario_pool.restype = C.c_int
     lib.mcn_orca_batch.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _f, _f, _vp]
@@ -126,13 +138,51 @@ def _load():
 lib = _load()
 
 # every symbol include/mcn.h declares; tests/test_abi.py checks the .so exports each one
-EXPORTED = ["mcn_version", "mcn_env_step", "mcn_env_rollout", "mcn_scenario_pool", "mcn_orca_batch", "mcn_pack_linear", "mcn_sarl_workspace_bytes",
+EXPORTED = ["mcn_version", "mcn_set_tuning", "mcn_get_tuning", "mcn_env_step", "mcn_env_rollout", "mcn_scenario_pool", "mcn_orca_batch", "mcn_pack_linear", "mcn_sarl_workspace_bytes",
             "mcn_sarl_lookahead", "mcn_sgan_workspace_bytes", "mcn_sgan_step"]
 
 
 def check(rc, what):
     if rc != MCN_OK:
         raise McnError("%s failed with code %d (%s)" % (what, rc, {-1: "MCN_EINVAL", -2: "MCN_ELAUNCH"}.get(rc, "?")))
+
+
+def get_tuning():
+    t = Tuning()
+    check(lib.mcn_get_tuning(C.byref(t)), "mcn_get_tuning")
+    return t
+
+
+def set_tuning(**kw):
+    """Override kernel dispatch (tests, tuning): set_tuning(quad_max_envs=0, force_generic=1); no arguments =
+    back to the initial (automatic / environment) values.  Returns the previous settings."""
+    prev = get_tuning()
+    if not kw:
+        check(lib.mcn_set_tuning(None), "mcn_set_tuning")
+        return prev
+    t = Tuning(force_generic=0, quad_max_envs=-1, quad_split=-1, rollout_fused=-1, rollout_split=-1,
+               rollout_octet=-1, diag_noop=0, reserved=0)
+    for k, v in kw.items():
+        if k not in dict(Tuning._fields_):
+            raise TypeError("unknown tuning field %r" % k)
+        setattr(t, k, int(v))
+    check(lib.mcn_set_tuning(C.byref(t)), "mcn_set_tuning")
+    return prev
+
+
+class tuned:
+    """Context manager: `with tuned(rollout_fused=1): ...` restores the previous dispatch on exit."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.prev = set_tuning(**self.kw)
+        return self
+
+    def __exit__(self, *exc):
+        check(lib.mcn_set_tuning(C.byref(self.prev)), "mcn_set_tuning")
+        return False
 
 
 def ptr(t):

@@ -21,6 +21,49 @@
 
 namespace mcn {
 
+// Diagnostic build only (make -C modelcrowdnav_amd/csrc stamp -> build_stamp/libmcn_hip.so, tools/fixed_cost.py):
+// lane 0 of every wavefront writes the 100 MHz real-time counter at kernel entry (slot 0), after the state load
+// (slot 1), at the end of each of its first 36 steps (slots 2..37) and at exit (slot 39) to a buffer nothing else
+// reads.  The product build compiles none of it.
+#ifdef MCN_DIAG
+#define MCN_STAMP_SLOTS 40
+#define MCN_STAMP_WAVES 8192
+__device__ unsigned long long g_stamps[MCN_STAMP_WAVES * MCN_STAMP_SLOTS];
+#define STAMP(slot)                                                                                              \
+    do {                                                                                                         \
+        const int w_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                                      \
+        if ((threadIdx.x & 63) == 0 && (slot) < MCN_STAMP_SLOTS && w_ < MCN_STAMP_WAVES)                         \
+            g_stamps[w_ * MCN_STAMP_SLOTS + (slot)] = __builtin_amdgcn_s_memrealtime();                          \
+    } while (0)
+// slot 38: where the wavefront ran -- HW_ID (wave / simd / cu / sh / se fields) in the low word, XCC_ID in the high
+#define STAMP_WHERE()                                                                                            \
+    do {                                                                                                         \
+        const int w_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                                      \
+        if ((threadIdx.x & 63) == 0 && w_ < MCN_STAMP_WAVES)                                                     \
+            g_stamps[w_ * MCN_STAMP_SLOTS + 38] =                                                                \
+                (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |                     \
+                ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32);             \
+    } while (0)
+int read_counts(void *dst, size_t bytes, int reset)
+{
+    if (bytes > sizeof(g_diag_counts)) bytes = sizeof(g_diag_counts);
+    const int rc = hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_diag_counts), bytes) == hipSuccess ? (int)(bytes / 4) : -1;
+    if (reset) {
+        void *sym = nullptr;
+        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_diag_counts)) == hipSuccess) (void)hipMemset(sym, 0, sizeof(g_diag_counts));
+    }
+    return rc;
+}
+int read_stamps(void *dst, size_t bytes)
+{
+    if (bytes > sizeof(g_stamps)) bytes = sizeof(g_stamps);
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), bytes) == hipSuccess ? (int)(bytes / 8) : -1;
+}
+#else
+#define STAMP(slot)
+#define STAMP_WHERE()
+#endif
+
 __device__ __forceinline__ int bperm_i(int byte_addr, int v) { return __builtin_amdgcn_ds_bpermute(byte_addr, v); }
 __device__ __forceinline__ float bperm_f(int byte_addr, float v)
 {
@@ -69,7 +112,11 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
     __shared__ double2 s_hpos[16], s_hvel[16], s_rpos[16], s_rvel[16];
     __shared__ double s_hrad[16];
     __shared__ int s_dn[16], s_case[16];
-    if (p.debug_noop) return;
+    STAMP(0);
+    STAMP_WHERE();
+#ifdef MCN_DIAG
+    if (p.debug_noop) return;      // diagnostic build only: launch-floor measurement
+#endif
     const int role = SPLIT ? (int)(threadIdx.x >> 6) : -1;      // 0: humans, 1: robot + ladder + records, -1: both
     const bool do_orca = role != 1, do_pair = role != 0;
     constexpr int NC = NT - 1 + VIS;          // candidates per human, <= 4
@@ -133,6 +180,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
     double o_rew = 0, o_dmin = 0;             // the step record of the latest step (stored once, after the loop)
     int o_dn = 0, o_inf = 0, o_hh = 0;
     double hax = 0, hay = 0;
+    STAMP(1);
 
     for (int t = 0; t < T; ++t) {
         const double2 act = act_next;
@@ -179,8 +227,9 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
                 // the exact test needs a float64 sqrt; it is skipped for the whole wavefront unless some counted
                 // pair is within 1e-6 of touching (a conservative screen: further apart, the exact test is false)
                 const double dx = pos.x - cpos.x, dy = pos.y - cpos.y;
-                const bool counted = (c.count_hh != 0) & cand_h & (j > h);
+                const bool counted = active & (c.count_hh != 0) & cand_h & (j > h);     // idle tail lanes alias env 0's humans
                 const double s2 = dx * dx + dy * dy, reach = rad + crd + 1e-6;
+                if (__any(counted & (s2 < reach * reach))) DIAG_COUNT(2);
                 if (__any(counted & (s2 < reach * reach)))
                     hh = (counted & ((sqrt(s2) - rad - crd) < 0)) ? 1 : 0;
             }
@@ -212,6 +261,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
             bool reaching = false;
             {
                 const double gx = endx - rgoal.x, gy = endy - rgoal.y, near = rrad + 1e-6;
+                if (__any(gx * gx + gy * gy < near * near)) DIAG_COUNT(3);
                 if (__any(gx * gx + gy * gy < near * near)) reaching = norm2(gx, gy) < rrad;
             }
             double rew; int inf;
@@ -286,6 +336,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
         // ---- humans: integrate, or restart from the scenario pool ----
         if (do_orca) {
             if (do_reset && dn) {
+                DIAG_COUNT(1);
                 if (active) {
                     const long pa = (long)case_g * NT + h;
                     const KernargPtr kp = kernarg_here();
@@ -311,6 +362,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
             __syncthreads();
             if (role == 1) { pos = s_hpos[hi]; vel = s_hvel[hi]; rad = s_hrad[hi]; }
         }
+        if (t < 37) STAMP(2 + t);
     }
 
     // ---- registers -> state (once per launch) ----
@@ -334,6 +386,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
         store_step_rec(p.out.rec + e, o_rew, o_dmin, o_dn, o_inf, o_hh);
         if (has_state) ro.state[e] = rs;
     }
+    STAMP(39);
 }
 
 template <int NT, int VIS, bool UNI>

@@ -49,7 +49,9 @@ __global__ __launch_bounds__(BLOCK)     // (forcing 8 waves/SIMD on the streamin
 void env_step_kernel(const StepParams p)
 {
     constexpr bool kStageHumans = (MODE == MCN_HUMANS_ORCA) || (HH_T != 0);
-    if (p.debug_noop) return;
+#ifdef MCN_DIAG
+    if (p.debug_noop) return;      // diagnostic build only: launch-floor measurement
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // carve (all offsets multiples of 16 B)
     float4  *sL      = reinterpret_cast<float4 *>(smem);                       // [nl_cap][BLOCK]

@@ -15,8 +15,8 @@ struct StepParams {
     int E, N, G, update, has_roll;
     int nl_cap;   // LDS line slots per lane
     int quad_max_envs;   // use the quad-parallel kernel up to this batch size (0: never)
-    int force_generic;   // MCN_FORCE_GENERIC=1: run-time-N kernel even where a specialisation exists (tests, tuning)
-    int debug_noop;      // MCN_DEBUG_NOOP=1: kernels return at entry (launch-floor measurement only)
+    int force_generic;   // mcn_tuning.force_generic: run-time-N kernel even where a specialisation exists (tests, tuning)
+    int debug_noop;      // mcn_tuning.diag_noop, DIAGNOSTIC BUILD ONLY: kernels return at entry (launch-floor measurement)
     int quad_split;      // quad kernel: ORCA and pairwise work on two cooperating wavefronts
 };
 

@@ -35,7 +35,9 @@ template <int NT, int VIS, bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? 128 : 64) void env_step_quad_kernel(const StepParams p)
 {
     __shared__ int s_dn[16], s_case[16];
-    if (p.debug_noop) return;
+#ifdef MCN_DIAG
+    if (p.debug_noop) return;      // diagnostic build only: launch-floor measurement
+#endif
     const int role = SPLIT ? (int)(threadIdx.x >> 6) : -1;      // 0: ORCA, 1: pairwise + ladder, -1: both
     const bool do_orca = role != 1, do_pair = role != 0;
     constexpr int NC = NT - 1 + VIS;          // candidates per human, <= 4

@@ -24,7 +24,38 @@ int launch_sgan(const mcn_sgan_net *net, double *hist, int push_slot, int oldest
 int launch_orca_batch(const float *self, const float *others, const int32_t *n_other, float *out,
                       int B, int M, float neighbor_dist, int max_neighbors, float time_horizon, float time_step,
                       hipStream_t stream);
+#ifdef MCN_DIAG
+int read_stamps(void *dst, size_t bytes);
+int read_counts(void *dst, size_t bytes, int reset);
+#endif
 }  // namespace mcn
+
+// Dispatch overrides (include/mcn.h: mcn_tuning).  The MCN_* environment variables are read ONCE, the first time a
+// launch needs them, as the initial values; after that only mcn_set_tuning changes them.  No getenv on the launch path.
+static mcn_tuning g_tuning;
+static bool g_tuning_init = false;
+static int env_or(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+static mcn_tuning tuning_from_env()
+{
+    mcn_tuning t;
+    memset(&t, 0, sizeof(t));
+    t.force_generic = env_or("MCN_FORCE_GENERIC", 0);
+    t.quad_max_envs = env_or("MCN_QUAD_MAX_ENVS", -1);
+    t.quad_split = env_or("MCN_QUAD_SPLIT", -1);
+    t.rollout_fused = env_or("MCN_ROLLOUT_FUSED", -1);
+    t.rollout_split = env_or("MCN_ROLLOUT_SPLIT", -1);
+    t.rollout_octet = env_or("MCN_ROLLOUT_OCTET", -1);
+    return t;
+}
+static const mcn_tuning &tuning()
+{
+    if (!g_tuning_init) { g_tuning = tuning_from_env(); g_tuning_init = true; }
+    return g_tuning;
+}
 
 // Validates one env-step problem and fills the kernel argument block.  Shared by mcn_env_step / mcn_env_rollout.
 static int fill_step_params(mcn::StepParams &p, const mcn_env_cfg *cfg, const mcn_env_state *st, const double *actions,
@@ -61,23 +92,45 @@ static int fill_step_params(mcn::StepParams &p, const mcn_env_cfg *cfg, const mc
     // grid still fits the chip about twice over (measured cross-over on MI355X: ~2800 wavefronts, i.e.
     // E <= 8192 at 5 humans); above that the lane-per-human kernel wins on throughput.  Inside the quad
     // kernel, ORCA and the float64 pairwise work go to two cooperating wavefronts only while BOTH still get a
-    // SIMD of their own (grid <= 512 workgroups).  MCN_QUAD_MAX_ENVS / MCN_QUAD_SPLIT override (tests, tuning).
-    const char *env_gen = getenv("MCN_FORCE_GENERIC");
-    p.force_generic = env_gen ? atoi(env_gen) : 0;
-    const char *env_noop = getenv("MCN_DEBUG_NOOP");
-    p.debug_noop = env_noop ? atoi(env_noop) : 0;
-    const char *env_max = getenv("MCN_QUAD_MAX_ENVS");
-    const char *env_split = getenv("MCN_QUAD_SPLIT");
+    // SIMD of their own (grid <= 512 workgroups).  mcn_set_tuning overrides (tests, tuning).
+    const mcn_tuning &tu = tuning();
+    p.force_generic = tu.force_generic > 0 ? 1 : 0;
+#ifdef MCN_DIAG
+    p.debug_noop = tu.diag_noop;
+#endif
     const int envs_per_wave = 64 / (4 * N);
     const long quad_waves = envs_per_wave > 0 ? ((long)E + envs_per_wave - 1) / envs_per_wave : (1L << 40);
-    p.quad_max_envs = env_max ? atoi(env_max) : (quad_waves <= 2800 ? E : 0);
-    p.quad_split = env_split ? atoi(env_split) : (quad_waves <= 512 ? 1 : 0);
+    p.quad_max_envs = tu.quad_max_envs >= 0 ? tu.quad_max_envs : (quad_waves <= 2800 ? E : 0);
+    p.quad_split = tu.quad_split >= 0 ? tu.quad_split : (quad_waves <= 512 ? 1 : 0);
     return MCN_OK;
 }
 
 extern "C" {
 
-const char *mcn_version(void) { return "modelcrowdnav_amd 0.1 (gfx950)"; }
+#ifdef MCN_DIAG
+const char *mcn_version(void) { return "modelcrowdnav_amd 0.2 (gfx950) DIAGNOSTIC BUILD (time stamps)"; }
+#else
+const char *mcn_version(void) { return "modelcrowdnav_amd 0.2 (gfx950)"; }
+#endif
+
+int mcn_set_tuning(const mcn_tuning *t)
+{
+    if (!t) { g_tuning = tuning_from_env(); g_tuning_init = true; return MCN_OK; }
+    if (t->quad_split > 1 || t->rollout_fused > 1 || t->rollout_split > 1 || t->force_generic < 0 || t->force_generic > 1) return MCN_EINVAL;
+#ifndef MCN_DIAG
+    if (t->diag_noop) return MCN_EINVAL;          // kernels that do nothing exist in the diagnostic build only
+#endif
+    g_tuning = *t;
+    g_tuning_init = true;
+    return MCN_OK;
+}
+
+int mcn_get_tuning(mcn_tuning *t)
+{
+    if (!t) return MCN_EINVAL;
+    *t = tuning();
+    return MCN_OK;
+}
 
 int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *actions,
                  const double *given_v, const mcn_env_out *out, const mcn_rollout *roll,
@@ -101,14 +154,13 @@ int mcn_env_rollout(const mcn_env_cfg *cfg, const mcn_env_state *st, const doubl
     // step at 49 152 envs, 13.9 vs 15.3 at 32 768), i.e. ~14 k env groups; below that the fused launch wins by up to
     // 2.7x.  Two cooperating wavefronts per env group while the doubled grid still finds idle issue slots (measured:
     // wins up to 1536 groups = 4608 envs, loses from 1707).
-    // MCN_ROLLOUT_FUSED=0/1 and MCN_ROLLOUT_SPLIT=0/1 override (tests, tuning).
-    const char *env_fused = getenv("MCN_ROLLOUT_FUSED");
-    const char *env_split = getenv("MCN_ROLLOUT_SPLIT");
+    // mcn_set_tuning (rollout_fused / rollout_split) overrides (tests, tuning).
+    const mcn_tuning &tu = tuning();
     const int envs_per_wave = 64 / (4 * N) > 0 ? 64 / (4 * N) : 1;
     const long waves = ((long)E + envs_per_wave - 1) / envs_per_wave;
-    const bool fused = env_fused ? atoi(env_fused) != 0 : waves <= 14000;
+    const bool fused = tu.rollout_fused >= 0 ? tu.rollout_fused != 0 : waves <= 14000;
     const int step_split = p.quad_split;              // the single-step kernel's own choice, for the T-launch path
-    p.quad_split = env_split ? atoi(env_split) : (waves <= 1536 ? 1 : 0);
+    p.quad_split = tu.rollout_split >= 0 ? tu.rollout_split : (waves <= 1536 ? 1 : 0);
     if (fused && !p.force_generic && mcn::launch_env_rollout_quad(p, T, (hipStream_t)stream))
         return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
     p.quad_split = step_split;
@@ -220,5 +272,12 @@ int mcn_sgan_step(const mcn_sgan_net *net, double *hist, int32_t push_slot, int3
     return mcn::launch_sgan(net, hist, push_slot, oldest, cur_pos, noise, hcount, workspace, out_vel, out_rel,
                             time_step, E, N, (hipStream_t)stream);
 }
+
+#ifdef MCN_DIAG
+// diagnostic build only: copies the rollout kernel's time stamps to host memory, returns the number of 8-byte words
+int mcn_debug_stamps(void *dst_host, int64_t bytes) { return mcn::read_stamps(dst_host, (size_t)bytes); }
+// per-wavefront counts of the data-dependent paths taken: [wave][4] = 3-D LP, restarts, overlap sqrt, goal sqrt
+int mcn_debug_counts(void *dst_host, int64_t bytes, int reset) { return mcn::read_counts(dst_host, (size_t)bytes, reset); }
+#endif
 
 }  // extern "C"

@@ -47,19 +47,19 @@ def _step_both(env, st, ax, ay, update, policy=cport.HUMANS_ORCA, given=None):
                                                  (32, False, False)])
 @pytest.mark.parametrize("update", [True, False])
 @pytest.mark.parametrize("kernel", ["auto", "lane-per-human", "run-time-N", "quad", "quad-split"])
-def test_step_matches_oracle_bitexact(N, visible, randomize, update, kernel, monkeypatch):
+def test_step_matches_oracle_bitexact(N, visible, randomize, update, kernel, tuning):
     # the same arithmetic exists in several decompositions (env_step.hip with compile-time or run-time N,
-    # env_step_quad.hip +- wavefront split); MCN_QUAD_* / MCN_FORCE_GENERIC pin which one the dispatcher picks
+    # env_step_quad.hip +- wavefront split); mcn_set_tuning (the `tuning` fixture) pins which one the dispatcher picks
     if kernel == "lane-per-human":
-        monkeypatch.setenv("MCN_QUAD_MAX_ENVS", "0")
+        tuning(quad_max_envs=0)
     elif kernel == "run-time-N":
-        monkeypatch.setenv("MCN_QUAD_MAX_ENVS", "0")
-        monkeypatch.setenv("MCN_FORCE_GENERIC", "1")
+        tuning(quad_max_envs=0)
+        tuning(force_generic=1)
     elif kernel.startswith("quad"):
         if N - 1 + int(visible) > 4:
             pytest.skip("quad kernel handles at most 4 neighbours")
-        monkeypatch.setenv("MCN_QUAD_MAX_ENVS", str(1 << 30))
-        monkeypatch.setenv("MCN_QUAD_SPLIT", "1" if kernel == "quad-split" else "0")
+        tuning(quad_max_envs=1 << 30)
+        tuning(quad_split=1 if kernel == "quad-split" else 0)
     rng = np.random.RandomState(100 + N + 7 * visible)
     E = 777   # ragged: not a multiple of the envs-per-wave count
     env = H.make_vec_env(E, N, robot_visible=visible)
@@ -143,9 +143,9 @@ def test_step_matches_reference_fixtures(name, policy, golden_dir):
 
 
 @pytest.mark.parametrize("kernel", ["auto", "lane-per-human"])
-def test_rollout_4096x5_bitexact_trajectory(kernel, monkeypatch):
+def test_rollout_4096x5_bitexact_trajectory(kernel, tuning):
     if kernel == "lane-per-human":
-        monkeypatch.setenv("MCN_QUAD_MAX_ENVS", "0")
+        tuning(quad_max_envs=0)
     _rollout_4096x5()
 
 
@@ -198,7 +198,7 @@ def _snapshot(env):
 @pytest.mark.parametrize("N,visible", [(5, False), (4, True), (3, False), (1, True), (2, False)])
 @pytest.mark.parametrize("with_pool", [True, False])
 @pytest.mark.parametrize("split", ["0", "1"])
-def test_rollout_launch_equals_single_steps(N, visible, with_pool, split, monkeypatch):
+def test_rollout_launch_equals_single_steps(N, visible, with_pool, split, tuning):
     """mcn_env_rollout (T steps in one launch, state in registers) == T mcn_env_step calls, every byte of state,
     step record, Explorer accounting and finished-episode records; episodes end and restart inside the sequence."""
     torch = _torch()
@@ -206,8 +206,8 @@ def test_rollout_launch_equals_single_steps(N, visible, with_pool, split, monkey
     rng = np.random.RandomState(N)
     sp, aa = rng.uniform(0, 1, (T, E)), rng.uniform(0, 2 * np.pi, (T, E))
     acts = torch.from_numpy(np.stack([sp * np.cos(aa), sp * np.sin(aa)], -1))
-    monkeypatch.setenv("MCN_ROLLOUT_FUSED", "1")
-    monkeypatch.setenv("MCN_ROLLOUT_SPLIT", split)     # one wavefront per env group / two cooperating ones
+    tuning(rollout_fused=1)
+    tuning(rollout_split=int(split))     # one wavefront per env group / two cooperating ones
     a = _rollout_env(E, N, visible, with_pool, fin_slots=2)
     b = _rollout_env(E, N, visible, with_pool, fin_slots=2)
     acts_d = acts.to(a.device)
@@ -219,7 +219,7 @@ def test_rollout_launch_equals_single_steps(N, visible, with_pool, split, monkey
     for k in sa:
         assert np.array_equal(sa[k].view(np.uint8), sb[k].view(np.uint8)), k
     assert int(a.rollout_buffers["fin_count"].min().item()) >= 1
-    monkeypatch.setenv("MCN_ROLLOUT_FUSED", "0")                # the T-launch path of the same entry point
+    tuning(rollout_fused=0)                # the T-launch path of the same entry point
     c = _rollout_env(E, N, visible, with_pool, fin_slots=2)
     c.rollout(acts_d)
     torch.cuda.synchronize()
@@ -229,15 +229,15 @@ def test_rollout_launch_equals_single_steps(N, visible, with_pool, split, monkey
 
 
 @pytest.mark.parametrize("split", ["0", "1"])
-def test_rollout_launch_unicycle_robot(split, monkeypatch):
+def test_rollout_launch_unicycle_robot(split, tuning):
     """The (v, r) robot (float64 sin / cos on the device, agent.py:110-135) through the fused launch: same code as the
     single step, so the same bytes; the trig-free holonomic kernel is a separate instantiation."""
     torch = _torch()
     E, N, T = 500, 5, 60
     rng = np.random.RandomState(8)
     acts = torch.from_numpy(np.stack([rng.uniform(0, 1, (T, E)), rng.uniform(-np.pi / 4, np.pi / 4, (T, E))], -1))
-    monkeypatch.setenv("MCN_ROLLOUT_FUSED", "1")
-    monkeypatch.setenv("MCN_ROLLOUT_SPLIT", split)
+    tuning(rollout_fused=1)
+    tuning(rollout_split=int(split))
     a = _rollout_env(E, N, False, True, kinematics="unicycle")
     b = _rollout_env(E, N, False, True, kinematics="unicycle")
     acts_d = acts.to(a.device)
@@ -285,11 +285,9 @@ def test_rollout_launch_matches_oracle_trajectory():
     rng = np.random.RandomState(3)
     sp, aa = rng.uniform(0, 1, (T, E)), rng.uniform(0, 2 * np.pi, (T, E))
     ax, ay = sp * np.cos(aa), sp * np.sin(aa)
-    os.environ["MCN_ROLLOUT_FUSED"] = "1"
-    try:
+    from modelcrowdnav_amd import _hip
+    with _hip.tuned(rollout_fused=1):
         env.rollout(torch.from_numpy(np.stack([ax, ay], -1)).to(env.device))
-    finally:
-        del os.environ["MCN_ROLLOUT_FUSED"]
     for t in range(T):
         ref = cport.env_step(cfg, st, ax[t], ay[t], update=True)
     H.assert_state_equal(H.download(env), st, what="after a %d-step launch" % T)
@@ -355,12 +353,12 @@ def test_unicycle_robot_matches_oracle_and_reference(golden_dir):
 
 
 @pytest.mark.parametrize("kernel", ["lane-per-human", "quad"])
-def test_degenerate_configurations_match_oracle(kernel, monkeypatch):
+def test_degenerate_configurations_match_oracle(kernel, tuning):
     """Edge cases the reference can reach: humans standing on their goal (zero preferred velocity), everybody at
     rest, agents overlapping or exactly coincident (the float32 solver then divides 0/0 -- the NaNs it produces
     must be the same NaNs), robot exactly on its goal, robot starting inside a human, zero robot action
     (degenerate swept segment).  Bit-exact including NaN positions."""
-    monkeypatch.setenv("MCN_QUAD_MAX_ENVS", "0" if kernel == "lane-per-human" else str(1 << 30))
+    tuning(quad_max_envs=0 if kernel == "lane-per-human" else 1 << 30)
     torch = _torch()
     rng = np.random.RandomState(2024)
     E, N = 240, 5

@@ -67,10 +67,11 @@ def main():
 
 
 def rollout_bench(a):
-    """Per-step time of the fused T-step launch (MCN_ROLLOUT_FUSED=1 forces it at any batch size)."""
+    """Per-step time of the fused T-step launch (mcn_set_tuning(rollout_fused=1) forces it at any batch size)."""
     dev = torch.device("cuda", 0)
     N, T = a.humans, a.rollout
-    os.environ["MCN_ROLLOUT_FUSED"] = "1"
+    from modelcrowdnav_amd import _hip
+    _hip.set_tuning(rollout_fused=1)
     for E in [int(x) for x in a.sizes.split(",")]:
         env, _ = bench.build_env(E, N, 0, dev)
         env.robot.visible = a.visible

@@ -11,7 +11,11 @@ A "step" is one CrowdSim.step of the whole batch.  The robot's actions are a pre
 steps go to the device as ceil(K / 1000) mcn_env_rollout launches (env state in registers between the steps
 of a launch; --steps-per-launch 1 = one mcn_env_step launch per step, also reported as single_step_launch).
 Inputs (states, the [K, E, 2] action tensor) are resident in HBM before the timed region; the launches are
-replayed from one hipGraph.
+replayed from one hipGraph.  When K steps take less than ~5 ms (the driver's --steps 20 is ~0.07 ms) the timed
+region holds R back-to-back passes of the same K steps (R chosen from an untimed probe pass, reported as
+config.replays; all R * K steps are executed on every env, none skipped) and ms_per_step = elapsed / (K * R).
+(Measured and dropped: stepping the shard as P independent sub-batches on P streams of one graph does not hide the
+straggling wavefronts of a launch -- a sub-batch launch is as latency-bound as the whole one.)
 Envs shard across ranks with no per-step communication (weak scaling); at the end of the
 rollout one RCCL all_gather collects episode returns + outcome codes.
 
@@ -55,6 +59,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the SARL / SGAN configurations")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--replays", type=int, default=0,
+                    help="passes of the K steps inside the timed region (0 = as many as fill --min-timed-ms)")
+    ap.add_argument("--min-timed-ms", type=float, default=5.0)
     return ap.parse_args()
 
 
@@ -127,21 +134,73 @@ def pairwise_bytes_per_env_step(N):
 _PMC = None
 
 
+def _profiles(pattern):
+    """Committed PMC summaries, oldest round first (later rounds override earlier ones)."""
+    import glob
+    out = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
+        try:
+            out.append((os.path.basename(f), json.load(open(f))))
+        except Exception:
+            pass
+    return out
+
+
 def pmc_traffic(E, given, steps_per_launch=1):
-    """HBM bytes per launch from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-    passes, gfx950 FETCH_SIZE x2 correction; profiles/r01_pmc_env_step.json).  None where no such run exists."""
+    """HBM bytes per launch from the committed PMC summaries (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    passes, gfx950 FETCH_SIZE x2 correction; profiles/rNN_pmc_env_step.json, rNN_pmc_env_rollout.json).
+    Returns (bytes, source): an exact (kernel kind, envs, steps per launch) match of the latest round, else for the
+    rollout kernel -- whose traffic is affine in the steps per launch (state once + one action per step) -- the
+    line through the two nearest measured launch lengths, else (None, None)."""
     global _PMC
     if _PMC is None:
-        _PMC = []
-        for name in ("r01_pmc_env_step.json", "r01_pmc_env_rollout.json"):
-            try:
-                _PMC += json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
-            except Exception:
-                pass
-    for k in _PMC:
-        if k["envs"] == E and ("pairwise-only" in k["what"]) == bool(given) and k.get("steps_per_launch", 1) == steps_per_launch:
-            return k["traffic_bytes_per_launch"]
-    return None
+        _PMC = {}
+        for fname, d in _profiles("r*_pmc_env_*.json"):
+            for k in d.get("kernels", []):
+                key = (k["envs"], "pairwise-only" in k["what"], int(k.get("steps_per_launch", 1)), "rollout" in k["kernel"])
+                _PMC[key] = (k["traffic_bytes_per_launch"], fname)
+    spl = int(round(steps_per_launch))
+    hit = _PMC.get((E, bool(given), spl, spl > 1))
+    if hit:
+        return hit[0], "PMC, %s" % hit[1]
+    if spl > 1:
+        pts = sorted((t, v[0], v[1]) for (e, g, t, ro), v in _PMC.items() if e == E and g == bool(given) and ro)
+        if len(pts) >= 2:
+            pts.sort(key=lambda x: abs(np.log(x[0] / spl)))
+            (t0, b0, f0), (t1, b1, _) = pts[0], pts[1]
+            by = b0 + (b1 - b0) * (spl - t0) / (t1 - t0)
+            return int(max(by, 0)), "affine in steps per launch through the PMC runs at %d and %d steps (%s)" % (t0, t1, f0)
+    return None, None
+
+
+VALU_PEAK_WAVE_INST_PER_S = 1024 * 2.4e9 / 2     # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz
+_SQ = None
+
+
+def valu_roofline(E, N, avg_ms, steps_per_launch, rollout, given=False):
+    """Instruction-issue roofline of a kernel that HBM does not bound: VALU wave-instructions per env-step from the
+    committed SQ_INSTS_VALU pass (profiles/rNN_pmc_sq.json) x env-steps per launch / the launch duration measured
+    live, against 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (float64 instructions occupy the pipe
+    for 4 cycles, so a float64-heavy kernel saturates below 1.0)."""
+    global _SQ
+    if _SQ is None:
+        _SQ = {}
+        for fname, d in _profiles("r*_pmc_sq*.json"):
+            for k in d.get("kernels", []):
+                _SQ[(k["kind"], k["envs"], k["humans"])] = (k, fname)
+    kind = "rollout" if rollout else ("pairwise" if given else "fused")
+    hit = _SQ.get((kind, E, N)) or (_SQ.get(("quad", E, N)) if kind == "fused" else None)
+    if hit is None:
+        return None
+    k, fname = hit
+    per_env_step = k["valu_per_env_step"]
+    ach = per_env_step * E * steps_per_launch / (avg_ms * 1e-3)
+    return {"bound": "valu-issue", "kernel": k["kernel"], "achieved": round(ach / 1e9, 2), "peak": round(VALU_PEAK_WAVE_INST_PER_S / 1e9, 1),
+            "unit": "G wave-instructions/s", "frac": round(ach / VALU_PEAK_WAVE_INST_PER_S, 4),
+            "valu_wave_instructions_per_env_step": round(per_env_step, 2),
+            "all_wave_instructions_per_env_step": round(k.get("insts_per_env_step", 0.0), 2),
+            "wave_cycles_waiting_frac": k.get("wait_frac"), "avg_launch_us": round(avg_ms * 1e3, 3),
+            "source": "SQ_INSTS_VALU etc. from %s (separate rocprofv3 --pmc pass), duration live" % fname}
 
 
 def roofline_entry(E, N, avg_ms, extra=None, given=False, steps_per_launch=1):
@@ -150,11 +209,13 @@ def roofline_entry(E, N, avg_ms, extra=None, given=False, steps_per_launch=1):
     ach = by / (avg_ms * 1e-3) / 1e9
     d = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(ach / HBM_PEAK_GBS, 5),
-         "traffic": pmc_traffic(E, given, steps_per_launch) if N == 5 else None,
+         "traffic": None, "traffic_source": None,
          "kernel": "mcn::env_step_kernel" if steps_per_launch == 1 else "mcn::env_rollout_quad_kernel",
          "envs_per_launch": E, "env_steps_per_launch": int(round(E * steps_per_launch)),
          "algorithmic_bytes_per_launch": int(round(by)),
          "avg_launch_us": round(avg_ms * 1e3, 3)}
+    if N == 5:
+        d["traffic"], d["traffic_source"] = pmc_traffic(E, given, steps_per_launch)
     if extra:
         d.update(extra)
     return d
@@ -240,7 +301,14 @@ def extra_configs(device):
         ms_sgan = _timed(lambda: world(env.hpos), 20)
         out.append({"config": "4096 envs x 10 humans, model-based rollout: SGAN (pool-net, zara1_8) world model + SARL robot",
                     "ms_per_step": round(ms4, 4), "env_steps_per_sec": round(E / ms4 * 1e3, 1),
-                    "sgan_step_ms": round(ms_sgan, 4)})
+                    "sgan_step_ms": round(ms_sgan, 4),
+                    # ~0.69 MFLOP per pedestrian for the pooling generator at N = 10 (8 encoder LSTM steps,
+                    # N pool-net MLPs 48 -> 512 -> 8 per pedestrian, context MLP, decoder LSTM step)
+                    "roofline": {"bound": "mfma", "kernel": "mcn::sgan_encode_kernel + mcn::sgan_decode_kernel",
+                                 "achieved": round(0.69e6 * E * N / ms_sgan / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": round(0.69e6 * E * N / ms_sgan / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
+                                 "traffic": None, "algorithmic_flop_per_launch": int(0.69e6 * E * N),
+                                 "avg_launch_us": round(ms_sgan * 1e3, 1), "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}})
     return out
 
 
@@ -258,8 +326,9 @@ def cpu_baseline(N, seconds):
     pool = S.scenario_pool(S.ScenarioSpec(), "test", range(500), N, "circle_crossing")
     sc, tab = pool[np.arange(E) % 500], action_table().numpy()
     n_env_steps, el, steps = cpu_replica.run(cpu_replica.setup(sc, tab, 0), seconds)
+    # the cores this process may run on (the GPU box gives one GPU's share of the host), not the host's total
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 16))                          # the GPU box gives one GPU's share of the host: 16 cores
+    cores = max(1, min(cores, 64))                          # bound the number of replica processes
     all_cores = None
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "workload.npz")
@@ -283,8 +352,8 @@ def cpu_baseline(N, seconds):
                          "sample": "%d independent replica processes of the same workload, %.1f s each, started "
                                    "together" % (len(good), secs)}
     return {"value": round(n_env_steps / el, 1), "unit": "env-steps/sec", "cores": 1, "kind": "port",
-            "sample": "%d envs x %d humans x %d steps (%.1f s), C oracle, 1 thread of %d host cores" % (
-                E, N, steps, el, os.cpu_count()),
+            "sample": "%d envs x %d humans x %d steps (%.1f s), C oracle, 1 thread; this process may use %d of the "
+                      "host's %d cores" % (E, N, steps, el, cores, os.cpu_count()),
             "all_cores": all_cores}
 
 
@@ -302,7 +371,6 @@ def main():
     cdev = device if backend == "nccl" else torch.device("cpu")        # where collective buffers live
     E, N, K, W = args.envs, args.humans, args.steps, args.warmup
     E_total = E * world
-
     env, pool = build_env(E, N, rank * E, device)
     acts = make_actions(W + K, E, E_total, rank * E, device)
 
@@ -326,13 +394,30 @@ def main():
     S = max(1, min(args.steps_per_launch, K))
     chunks = [(t, min(S, K - t)) for t in range(0, K, S)]
 
-    def run_timed_steps():
+    def one_pass():
+        """The K timed steps."""
         if S == 1:
             for t in range(K):
                 env.step(acts[W + t])
         else:
             for t, n in chunks:
                 env.rollout(acts[W + t:W + t + n])
+
+    # untimed probe pass (an extra warm-up of K steps): how many passes fill the minimum timed region?
+    ev_s, ev_e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    one_pass()
+    torch.cuda.synchronize()
+    ev_s.record()
+    one_pass()
+    ev_e.record()
+    torch.cuda.synchronize()
+    probe_ms = ev_s.elapsed_time(ev_e)
+    R = args.replays if args.replays > 0 else int(min(20000, max(1, np.ceil(args.min_timed_ms / max(probe_ms, 1e-3)))))
+
+    def run_timed_steps():
+        """R back-to-back passes of the K steps."""
+        for _ in range(R):
+            one_pass()
 
     use_graph = not args.no_graph
     if use_graph:
@@ -342,7 +427,6 @@ def main():
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             run_timed_steps()
 
-    rb = env.rollout_buffers
     gathered = None
     if world > 1:
         import torch.distributed as dist
@@ -360,7 +444,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ev_s, ev_e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
     ev_s.record()
@@ -371,16 +454,22 @@ def main():
     ev_e.record()
     if world > 1:
         # the path's one exchange: episode returns + outcome codes + counts, one fused buffer, one collective
+        rb = env.rollout_buffers
         packed = torch.stack([rb["fin_return"][0], rb["fin_info"][0].double(), rb["fin_count"].double()], 1).float()
         dist.all_gather_into_tensor(gathered, packed.to(cdev))
     barrier()
     elapsed = time.perf_counter() - t0
+    env_steps_total = float(E * K * R)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    # dominant-kernel duration: HIP events (launch stream) bracketing the K back-to-back launches of the timed region
-    n_launch = K if S == 1 else len(chunks)
+        # each rank chose its own pass count R from its own probe: the job's work is the sum over ranks
+        ws = torch.tensor([env_steps_total], dtype=torch.float64, device=cdev)
+        dist.all_reduce(ws, op=dist.ReduceOp.SUM)
+        env_steps_total = float(ws.item())
+    # dominant-kernel duration: HIP events (launch stream) bracketing the back-to-back launches of the timed region
+    n_launch = (K if S == 1 else len(chunks)) * R
     kernel_ms = ev_s.elapsed_time(ev_e) / n_launch
 
     rb = env.rollout_buffers
@@ -388,35 +477,39 @@ def main():
     mean_ret = float(rb["fin_return"][0][rb["fin_count"] > 0].mean().item()) if episodes else float("nan")
 
     roof = roofline_entry(E, N, kernel_ms, {"timing": "HIP events around the %d launches of the timed region (%s)" % (
-        n_launch, "one hipGraph" if use_graph else "eager")}, steps_per_launch=K / n_launch)
+        n_launch, "one hipGraph" if use_graph else "eager")}, steps_per_launch=K * R / n_launch)
     if S > 1:
         # state lives in registers across the steps of a launch: HBM sees the state once per launch, not per step
         roof["note"] = ("algorithmic bytes = SURVEY 8(d) per-env-step figure x env-steps per launch; a launch keeps the "
                         "env state in registers for its %d steps, so real HBM traffic (`traffic`) is a fraction of "
-                        "that and the kernel is instruction-issue-bound, not HBM-bound" % S)
+                        "that and the kernel is instruction-issue / latency-bound, not HBM-bound: see roofline_valu" % S)
+    valu = valu_roofline(E, N, kernel_ms, K * R / n_launch, rollout=S > 1)
 
     result = {
         "metric": "env-steps/sec (whole node), 5-human CrowdSim x batched envs",
-        "value": round(E_total * K / elapsed, 1), "unit": "env-steps/sec",
-        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 6),
+        "value": round(env_steps_total / elapsed, 1), "unit": "env-steps/sec",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / (env_steps_total / E_total) * 1e3, 6),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "%d envs x %d humans per GPU, ORCA humans, random robot actions (81-entry table), "
                                "auto-reset, %s" % (E, N, "1 mcn_env_step launch per step" if S == 1 else
                                                    "%d steps per mcn_env_rollout launch" % S),
-                   "steps_per_launch": S,
+                   "steps_per_launch": S, "replays": R, "timed_steps": K * R,
+                   "timed_region_ms": round(elapsed * 1e3, 3), "probe_pass_ms": round(probe_ms, 4),
                    "envs_per_gpu": E, "humans": N, "launch": "hipGraph" if use_graph else "eager",
                    "parallelism": "env-shard x%d, no per-step collective" % world},
         "episodes_finished": episodes, "mean_discounted_return": round(mean_ret, 6),
         "gathered_episode_records": None if gathered is None else int((gathered[:, 2] > 0).sum().item()),
         "roofline": roof,
+        "roofline_valu": valu,
     }
 
     if rank == 0 and world == 1 and S > 1:
         # the same workload stepped one mcn_env_step launch at a time (policy-in-the-loop callers pay this)
         one_ms, _ = time_kernel_events(env, acts, 200)
         result["single_step_launch"] = roofline_entry(E, N, one_ms, {
-            "mode": "one mcn_env_step launch per step, hipGraph of 200", "env_steps_per_sec": round(E / (one_ms * 1e-3), 1)})
+            "mode": "one mcn_env_step launch per step, hipGraph of 200", "env_steps_per_sec": round(E / (one_ms * 1e-3), 1),
+            "roofline_valu": valu_roofline(E, N, one_ms, 1, rollout=False)})
 
     if rank == 0 and world == 1 and not args.no_sweep:
         sweep = []
@@ -430,12 +523,15 @@ def main():
             torch.cuda.synchronize()
             a_ms, _ = time_kernel_events(env_s, a_s, 50)
             sweep.append(roofline_entry(Es, N, a_ms, {"mode": "fused ORCA + pairwise + reward + integrate",
-                                                       "env_steps_per_sec": round(Es / (a_ms * 1e-3), 1)}))
+                                                       "env_steps_per_sec": round(Es / (a_ms * 1e-3), 1),
+                                                       "roofline_valu": valu_roofline(Es, N, a_ms, 1, rollout=False)}))
             gv = torch.rand(Es, N, 2, dtype=torch.float64, device=device) - 0.5
             g_ms, _ = time_kernel_events(env_s, a_s, 50, given_v=gv)
             sweep.append(roofline_entry(Es, N, g_ms, {"mode": "pairwise + reward + integrate (given velocities, "
                                                               "ModelCrowdSim.step)",
-                                                       "env_steps_per_sec": round(Es / (g_ms * 1e-3), 1)}, given=True))
+                                                       "env_steps_per_sec": round(Es / (g_ms * 1e-3), 1),
+                                                       "roofline_valu": valu_roofline(Es, N, g_ms, 1, rollout=False, given=True)},
+                                        given=True))
             env_s.detach_rollout()          # SURVEY 8(d) "pairwise kernel alone": no Explorer record, no restart
             n_ms, _ = time_kernel_events(env_s, a_s, 50, given_v=gv)
             sweep.append(roofline_entry(Es, N, n_ms, {"mode": "pairwise + reward + integrate, no Explorer record / "

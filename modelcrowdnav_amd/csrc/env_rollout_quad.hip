@@ -366,25 +366,34 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
     }
 
     // ---- registers -> state (once per launch) ----
-    if (hlead) {
-        reinterpret_cast<double2 *>(p.st.hpos)[a] = pos;
-        reinterpret_cast<double2 *>(p.st.hvel)[a] = vel;
-        if (do_reset) {
-            reinterpret_cast<double2 *>(p.st.hgoal)[a] = goal;
-            p.st.hrad[a] = rad;
-            p.st.hvpref[a] = vpref;
+    // Addresses and pointers are re-derived here from laundered indices and a fresh read of the kernel arguments:
+    // shared with the prologue's they would stay live across the step loop and spill to scratch.
+    {
+        long a2 = a, e2 = e;
+        asm volatile("" : "+v"(a2), "+v"(e2));
+        const KernargPtr kp = kernarg_here();
+        if (hlead) {
+            reinterpret_cast<double2 *>(kp->st.hpos)[a2] = pos;
+            reinterpret_cast<double2 *>(kp->st.hvel)[a2] = vel;
+            if (do_reset) {
+                reinterpret_cast<double2 *>(kp->st.hgoal)[a2] = goal;
+                kp->st.hrad[a2] = rad;
+                kp->st.hvpref[a2] = vpref;
+            }
+            double *human_times = kp->st.human_times, *human_act = kp->out.human_act;
+            if (human_times) human_times[a2] = htime;
+            if (human_act) reinterpret_cast<double2 *>(human_act)[a2] = make_double2(hax, hay);
         }
-        if (p.st.human_times) p.st.human_times[a] = htime;
-        if (p.out.human_act) reinterpret_cast<double2 *>(p.out.human_act)[a] = make_double2(hax, hay);
-    }
-    if (lead) {
-        reinterpret_cast<double2 *>(p.st.rpos)[e] = rpos;
-        reinterpret_cast<double2 *>(p.st.rvel)[e] = rvel;
-        if (do_reset) reinterpret_cast<double2 *>(p.st.rgoal)[e] = rgoal;
-        if (p.st.rtheta) p.st.rtheta[e] = rtheta;
-        p.st.gtime[e] = gtime;
-        store_step_rec(p.out.rec + e, o_rew, o_dmin, o_dn, o_inf, o_hh);
-        if (has_state) ro.state[e] = rs;
+        if (lead) {
+            reinterpret_cast<double2 *>(kp->st.rpos)[e2] = rpos;
+            reinterpret_cast<double2 *>(kp->st.rvel)[e2] = rvel;
+            if (do_reset) reinterpret_cast<double2 *>(kp->st.rgoal)[e2] = rgoal;
+            double *rth = kp->st.rtheta;
+            if (rth) rth[e2] = rtheta;
+            kp->st.gtime[e2] = gtime;
+            store_step_rec(kp->out.rec + e2, o_rew, o_dmin, o_dn, o_inf, o_hh);
+            if (has_state) kp->roll.state[e2] = rs;
+        }
     }
     STAMP(39);
 }

@@ -210,7 +210,8 @@ def roofline_entry(E, N, avg_ms, extra=None, given=False, steps_per_launch=1):
     d = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(ach / HBM_PEAK_GBS, 5),
          "traffic": None, "traffic_source": None,
-         "kernel": "mcn::env_step_kernel" if steps_per_launch == 1 else "mcn::env_rollout_quad_kernel",
+         "kernel": ("mcn::env_pair_kernel" if given and N in (5, 10) and E > 4096 * (64 // N) else "mcn::env_step_kernel")
+         if steps_per_launch == 1 else "mcn::env_rollout_quad_kernel",
          "envs_per_launch": E, "env_steps_per_launch": int(round(E * steps_per_launch)),
          "algorithmic_bytes_per_launch": int(round(by)),
          "avg_launch_us": round(avg_ms * 1e3, 3)}
@@ -526,6 +527,7 @@ def main():
                                                        "env_steps_per_sec": round(Es / (a_ms * 1e-3), 1),
                                                        "roofline_valu": valu_roofline(Es, N, a_ms, 1, rollout=False)}))
             gv = torch.rand(Es, N, 2, dtype=torch.float64, device=device) - 0.5
+            env_s.count_hh = False          # ModelCrowdSim.step has no human-human check (model_crowd_sim.py:347-441)
             g_ms, _ = time_kernel_events(env_s, a_s, 50, given_v=gv)
             sweep.append(roofline_entry(Es, N, g_ms, {"mode": "pairwise + reward + integrate (given velocities, "
                                                               "ModelCrowdSim.step)",

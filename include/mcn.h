@@ -286,7 +286,7 @@ int mcn_sgan_step(const mcn_sgan_net *net, double *hist, int32_t push_slot, int3
  * Dispatch overrides (host, process-wide, not stream-ordered; for tests and tuning).  Every env-step arithmetic
  * exists in several kernel decompositions with bit-identical results; by default the entry points pick one from
  * the batch shape.  -1 = automatic.  The MCN_FORCE_GENERIC / MCN_QUAD_MAX_ENVS / MCN_QUAD_SPLIT /
- * MCN_ROLLOUT_FUSED / MCN_ROLLOUT_SPLIT environment variables give the initial values and are read once, at
+ * MCN_ROLLOUT_FUSED / MCN_ROLLOUT_SPLIT / MCN_PAIR_STREAM environment variables give the initial values and are read once, at
  * the first launch; no entry point calls getenv after that.
  */
 typedef struct mcn_tuning {
@@ -297,7 +297,7 @@ typedef struct mcn_tuning {
     int32_t rollout_split;   /* fused rollout: two cooperating wavefronts per env group (0/1) */
     int32_t rollout_octet;   /* reserved for the many-lanes-per-human forms (-1 / 0 / 1) */
     int32_t diag_noop;       /* DIAGNOSTIC build only (make stamp): env kernels return at entry; MCN_EINVAL otherwise */
-    int32_t reserved;
+    int32_t pair_stream;     /* given-velocity step: streaming kernel (env_pair.hip) 1 wherever it applies / 0 never */
 } mcn_tuning;
 
 /* NULL restores the initial values.  Returns MCN_EINVAL for out-of-range fields. */

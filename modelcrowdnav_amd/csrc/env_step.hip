@@ -374,6 +374,7 @@ static void dispatch(const StepParams &p, int blocks, hipStream_t stream)
 }
 
 bool launch_env_step_quad(const StepParams &p, hipStream_t stream);      // env_step_quad.hip
+bool launch_env_pair(const StepParams &p, hipStream_t stream);           // env_pair.hip
 
 int launch_env_step(const StepParams &p, hipStream_t stream)
 {
@@ -381,6 +382,9 @@ int launch_env_step(const StepParams &p, hipStream_t stream)
     if (p.quad_max_envs > 0 && p.E <= p.quad_max_envs && launch_env_step_quad(p, stream))
         return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
     const int waves_total = (p.E + p.G - 1) / p.G;
+    // given velocities, large batch: the streaming form (env_pair.hip); mcn_tuning.pair_stream overrides
+    if ((p.pair_stream > 0 || (p.pair_stream < 0 && waves_total > 4096)) && launch_env_pair(p, stream))
+        return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
     // small batches: one wavefront per workgroup so the grid covers as many CUs as possible
     if (waves_total <= 4096) dispatch<64>(p, waves_total, stream);
     else                     dispatch<256>(p, (waves_total + 3) / 4, stream);

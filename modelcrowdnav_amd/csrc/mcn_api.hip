@@ -49,6 +49,7 @@ static mcn_tuning tuning_from_env()
     t.rollout_fused = env_or("MCN_ROLLOUT_FUSED", -1);
     t.rollout_split = env_or("MCN_ROLLOUT_SPLIT", -1);
     t.rollout_octet = env_or("MCN_ROLLOUT_OCTET", -1);
+    t.pair_stream = env_or("MCN_PAIR_STREAM", -1);
     return t;
 }
 static const mcn_tuning &tuning()
@@ -95,6 +96,7 @@ static int fill_step_params(mcn::StepParams &p, const mcn_env_cfg *cfg, const mc
     // SIMD of their own (grid <= 512 workgroups).  mcn_set_tuning overrides (tests, tuning).
     const mcn_tuning &tu = tuning();
     p.force_generic = tu.force_generic > 0 ? 1 : 0;
+    p.pair_stream = tu.pair_stream;
 #ifdef MCN_DIAG
     p.debug_noop = tu.diag_noop;
 #endif
@@ -116,7 +118,7 @@ const char *mcn_version(void) { return "modelcrowdnav_amd 0.2 (gfx950)"; }
 int mcn_set_tuning(const mcn_tuning *t)
 {
     if (!t) { g_tuning = tuning_from_env(); g_tuning_init = true; return MCN_OK; }
-    if (t->quad_split > 1 || t->rollout_fused > 1 || t->rollout_split > 1 || t->force_generic < 0 || t->force_generic > 1) return MCN_EINVAL;
+    if (t->quad_split > 1 || t->rollout_fused > 1 || t->rollout_split > 1 || t->pair_stream > 1 || t->force_generic < 0 || t->force_generic > 1) return MCN_EINVAL;
 #ifndef MCN_DIAG
     if (t->diag_noop) return MCN_EINVAL;          // kernels that do nothing exist in the diagnostic build only
 #endif

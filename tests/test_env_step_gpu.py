@@ -96,6 +96,57 @@ def test_given_velocity_and_linear_modes():
     np.testing.assert_allclose(d.hpx, ref_st.hpx, rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("N", [5, 10])
+@pytest.mark.parametrize("book", ["pool", "record", "none"])
+def test_streaming_pair_kernel_equals_lane_per_human(N, book, tuning):
+    """env_pair.hip (given velocities, per-env data loaded / stored in 16-byte pieces by all lanes of the env, ladder
+    and Explorer record on every lane) against env_step_kernel<GIVEN>: every byte of state, step record, Explorer
+    record and finished-episode records over 130 steps with collisions, goals, timeouts and pool restarts; the first
+    step also against the C oracle."""
+    torch = _torch()
+    E, T = 1003, 130
+    rng = np.random.RandomState(40 + N)
+
+    def make():
+        if book == "none":
+            env = H.make_vec_env(E, N)
+            from modelcrowdnav_amd.envs import scenarios as S
+            env.load_scenarios(S.scenario_pool(env.spec(), "test", range(64), N, "circle_crossing")[np.arange(E) % 64])
+        else:
+            env = _rollout_env(E, N, False, book == "pool", fin_slots=2)
+        env.count_hh = False
+        return env
+    a, b = make(), make()
+    # robots head for their goal (0, 4) with some noise; humans drift across the circle
+    ang = rng.uniform(0, 2 * np.pi, (T, E, N))
+    gv = torch.from_numpy(np.stack([0.6 * np.cos(ang), 0.6 * np.sin(ang)], -1)).to(a.device)
+    acts = torch.from_numpy(np.stack([rng.uniform(-0.3, 0.3, (T, E)), rng.uniform(0.2, 1.0, (T, E))], -1)).to(a.device)
+    st0 = H.download(a)
+    for t in range(T):
+        tuning(pair_stream=1)
+        a.step(acts[t], given_v=gv[t])
+        tuning(pair_stream=0)
+        b.step(acts[t], given_v=gv[t])
+        if t == 0:
+            ref = cport.env_step(H.oracle_cfg_for(a, cport.HUMANS_GIVEN), st0, acts[0, :, 0].cpu().numpy().copy(),
+                                 acts[0, :, 1].cpu().numpy().copy(), update=True, given_v=gv[0].cpu().numpy())
+            assert np.array_equal(a.done.cpu().numpy(), ref["done"]) and np.array_equal(a.reward.cpu().numpy(), ref["reward"])
+            assert np.array_equal(a.dmin.cpu().numpy(), ref["dmin"]) and np.array_equal(a.info.cpu().numpy(), ref["info"])
+            if book != "pool":
+                H.assert_state_equal(H.download(a), st0, what="streaming pair kernel vs oracle")
+        if t % 13 == 0 or t == T - 1:
+            torch.cuda.synchronize()
+            sa, sb = _snapshot(a) if book != "none" else None, _snapshot(b) if book != "none" else None
+            if book == "none":
+                for k in ("hpos", "hvel", "rpos", "rvel", "gtime", "step_rec"):
+                    assert np.array_equal(getattr(a, k).cpu().numpy().view(np.uint8), getattr(b, k).cpu().numpy().view(np.uint8)), (k, t)
+            else:
+                for k in sa:
+                    assert np.array_equal(sa[k].view(np.uint8), sb[k].view(np.uint8)), (k, t)
+    if book != "none":
+        assert int(a.rollout_buffers["fin_count"].sum().item()) > E // 2
+
+
 @pytest.mark.parametrize("name,policy", [("g2_step_given", cport.HUMANS_GIVEN), ("g2_step_linear", cport.HUMANS_LINEAR),
                                          ("g2_step_orca", cport.HUMANS_ORCA),
                                          ("g2_step_orca_visible", cport.HUMANS_ORCA)])

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--sizes", default="4096,65536,1048576")
     ap.add_argument("--modes", default="orca,given")
     ap.add_argument("--visible", action="store_true")
+    ap.add_argument("--no-hh", action="store_true", help="no human-human overlap count (ModelCrowdSim.step does not count)")
+    ap.add_argument("--pair-stream", type=int, default=-1, help="mcn_tuning.pair_stream")
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--sarl", action="store_true")
     ap.add_argument("--rollout", type=int, default=0, help="time mcn_env_rollout with this many steps per launch")
@@ -37,6 +39,11 @@ def main():
     for E in [int(x) for x in a.sizes.split(",")]:
         env, _ = bench.build_env(E, N, 0, dev)
         env.robot.visible = a.visible
+        if a.no_hh:
+            env.count_hh = False
+        if a.pair_stream >= 0:
+            from modelcrowdnav_amd import _hip
+            _hip.set_tuning(pair_stream=a.pair_stream)
         acts = bench.make_actions(16, E, E, 0, dev)
         gv = torch.rand(E, N, 2, dtype=torch.float64, device=dev) - 0.5
         for mode in a.modes.split(","):

@@ -44,6 +44,9 @@ _MAP = {
     "crowd_nav.utils.explorer": "modelcrowdnav_amd.utils.explorer",
     "crowd_nav.utils.memory": "modelcrowdnav_amd.utils.memory",
     "crowd_nav.utils.trainer": "modelcrowdnav_amd.utils.trainer",
+    "crowd_nav.utils.trainer_sim": "modelcrowdnav_amd.utils.trainer_sim",
+    "crowd_nav.utils.datagen": "modelcrowdnav_amd.utils.datagen",
+    "crowd_nav.utils.misc": "modelcrowdnav_amd.utils.misc",
     "sgan.models": "modelcrowdnav_amd.sgan.models",
     "sgan.utils": "modelcrowdnav_amd.sgan.utils",
 }

@@ -3,8 +3,8 @@
 Reference surface kept (crowd_sim/envs/crowd_sim.py): configure :58, set_robot :91,
 reset :261, step :331, onestep_lookahead :325, plus the attributes its callers read
 (case_size, case_counter, human_num, time_step, time_limit, global_time, humans, robot, states,
-sim_world, device, test_sim).  render / get_human_times are host-only visual tooling and are
-out of scope.
+sim_world, device, test_sim), get_human_times :219 (an all-ORCA simulation to the end: one mcn_orca_batch
+launch per simulated step).  render is host-only visual tooling and out of scope.
 
   VecCrowdSim  tensors in / tensors out, E envs, SoA float64 state (layout: include/mcn.h)
   CrowdSim     the E = 1 gym-style view returning the reference's value types
@@ -524,6 +524,60 @@ class CrowdSim(object):
 
     def _vec_step(self, actions, update):
         return self._vec.step(actions, update=update)
+
+    def get_human_times(self, max_steps=8000):
+        """crowd_sim.py:219-258: once the robot has arrived, run everybody (robot = agent 0, then the humans) to the end
+        in ONE centralised ORCA simulation and return each human's first-arrival time.  The reference drives an
+        rvo2.PyRVOSimulator(time_step, 10, 10, 5, 5, 0.3, 1) with agents at their own radius / v_pref; here every
+        simulated step is one mcn_orca_batch launch (B = N + 1 agents, each with the other N as candidates in index
+        order) and the float32 position update rvo2 does inside doStep (velocity = newVelocity; position += velocity *
+        timeStep) is done on the host copies in float32.  ORCA parity vs rvo2 is unpinned (oracle/mcn_oracle.c); rvo2
+        enumerates neighbours in kd-tree order, which only matters for exactly equal distances.
+        The reference loops for ever if somebody never arrives (it only logs past t = 1000); this stops after
+        `max_steps` simulated steps with the same warning."""
+        v, robot = self._vec, self._vec.robot
+        if not robot.reached_destination():
+            raise ValueError("Episode is not done yet")
+        agents = [robot] + self.humans
+        B, f32, dev = len(agents), np.float32, v.device
+        M = B - 1
+        pos = np.array([a.get_position() for a in agents], np.float64).astype(f32)
+        vel = np.array([a.get_velocity() for a in agents], np.float64).astype(f32)
+        rad = np.array([a.radius for a in agents], np.float64).astype(f32)
+        vmax = np.array([a.v_pref for a in agents], np.float64).astype(f32)
+        dt32 = f32(v.time_step)
+        others_idx = np.array([[j for j in range(B) if j != i] for i in range(B)], np.int64).reshape(B, M)
+        d_n = torch.full((B,), M, dtype=torch.int32, device=dev)
+        d_out = torch.empty(B, 2, dtype=torch.float32, device=dev)
+        max_time, steps = 1000, 0
+        while not all(self.human_times):
+            pref = np.zeros((B, 2), np.float64)
+            for i, agent in enumerate(agents):
+                vel_pref = np.array(agent.get_goal_position()) - np.array(agent.get_position())
+                if np.linalg.norm(vel_pref) > 1:
+                    vel_pref /= np.linalg.norm(vel_pref)
+                pref[i] = vel_pref
+            me = np.concatenate([pos, vel, rad[:, None], vmax[:, None], pref.astype(f32)], 1).astype(f32)       # [B,8]
+            oth = np.concatenate([pos[others_idx], vel[others_idx], rad[others_idx][..., None]], 2).astype(f32)  # [B,M,5]
+            d_me, d_oth = torch.from_numpy(me).to(dev), torch.from_numpy(np.ascontiguousarray(oth)).to(dev)
+            _hip.check(_hip.lib.mcn_orca_batch(_hip.ptr(d_me), _hip.ptr(d_oth), _hip.ptr(d_n), _hip.ptr(d_out), B, max(M, 1),
+                                               10.0, 10, 5.0, float(v.time_step), _hip.stream_ptr(dev)), "mcn_orca_batch")
+            vel = d_out.cpu().numpy().astype(f32)
+            pos = (pos + vel * dt32).astype(f32)
+            self.global_time += v.time_step
+            steps += 1
+            if self.global_time > max_time:
+                logging.warning("Simulation cannot terminate!")
+            for i, human in enumerate(self.humans):
+                if self.human_times[i] == 0 and human.reached_destination():
+                    self.human_times[i] = self.global_time
+            robot.set_position((float(pos[0, 0]), float(pos[0, 1])))
+            for i, human in enumerate(self.humans):
+                human.set_position((float(pos[i + 1, 0]), float(pos[i + 1, 1])))
+            self.states.append([robot.get_full_state(), [h.get_full_state() for h in self.humans]])
+            if steps >= max_steps:
+                break
+        return self.human_times
 
     def render(self, mode="human", output_file=None, render_weight=False):
         raise NotImplementedError("render is matplotlib host tooling, out of scope for this build (SURVEY.md 2)")

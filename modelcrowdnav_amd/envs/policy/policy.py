@@ -1,6 +1,8 @@
 """Policy base class (reference: crowd_sim/envs/policy/policy.py:5-49)."""
 import math
 
+import numpy as np
+
 
 class Policy(object):
     def __init__(self):
@@ -33,4 +35,6 @@ class Policy(object):
     @staticmethod
     def reach_destination(state):
         s = state.self_state
-        return math.hypot(s.py - s.gy, s.px - s.gx) < s.radius
+        # numpy's 2-vector norm, as the reference (policy.py:46): sqrt(fma(x1, x1, x0 * x0)) on this image, the
+        # formula the batched kernels and the oracle use -- not math.hypot, which can differ in the last bit
+        return np.linalg.norm((s.py - s.gy, s.px - s.gx)) < s.radius

@@ -135,7 +135,9 @@ class MultiHumanRL(CADRL):
 
     # ------------------------------------------------------------------ batched surface
     def predict_batch(self, env, want_values=False, hcount=None):
-        """Greedy look-ahead for all E environments of a VecCrowdSim (phase 'test'/'val').
+        """Look-ahead for all E environments of a VecCrowdSim: greedy in phase 'test' / 'val'; in phase 'train' each
+        env independently takes a uniformly random table action with probability `epsilon` (multi_human_rl.py:27-29,
+        one draw per env per step from torch's device generator) -- `best` is -2 for those envs.
 
         Returns (actions [E,2] float64 device tensor, best [E] int32; -1 where the robot already
         stands on its goal and the zero action is returned, multi_human_rl.py:22-23).
@@ -153,8 +155,17 @@ class MultiHumanRL(CADRL):
             st.hcount = _hip.ptr(hcount)
         values, best, best_val, _ = self._lookahead(st, env.num_envs, env._alloc_N, dev)
         table = self._bufs["table"]
-        idx = best.clamp(min=0).long()
-        actions = table[idx] * (best >= 0).unsqueeze(1).to(table.dtype)
+        eps = float(getattr(self, "epsilon", 0) or 0)
+        if self.phase == "train" and eps > 0:
+            E = env.num_envs
+            explore = (torch.rand(E, device=dev) < eps) & (best >= 0)        # a robot on its goal returns before the draw
+            ridx = torch.randint(0, table.shape[0], (E,), device=dev, dtype=best.dtype)
+            best = torch.where(explore, torch.full_like(best, -2), best)
+            idx = torch.where(explore, ridx, best.clamp(min=0)).long()
+            actions = table[idx] * (best != -1).unsqueeze(1).to(table.dtype)
+        else:
+            idx = best.clamp(min=0).long()
+            actions = table[idx] * (best >= 0).unsqueeze(1).to(table.dtype)
         if want_values:
             return actions, best, values
         return actions, best

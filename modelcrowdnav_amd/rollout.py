@@ -166,8 +166,11 @@ class VecExplorer(object):
                                             for r in range(rounds - 1)):
                 raise NotImplementedError("non-uniform case stride (k wraps the case list unevenly)")
             stride = int(d[0])
+        # at least two finished-episode slots: with one the kernel keeps the LATEST episode of an env (mcn.h), and an env
+        # that finishes early keeps replaying its case until the slowest env is done -- with a stochastic robot
+        # (epsilon-greedy, random action_fn) the record would then describe the last repeat instead of the first run
         bufs = env.attach_rollout(self.gamma, pool=pool, case_stride=stride,
-                                  first_cases=(mine[:, 1] if rounds > 1 else mine[:, 0]), fin_slots=rounds)
+                                  first_cases=(mine[:, 1] if rounds > 1 else mine[:, 0]), fin_slots=max(rounds, 2))
         horizon = int(round(env.time_limit / env.time_step)) + 2
         limit = max_steps if max_steps is not None else rounds * horizon
         if update_memory and (self.memory is None or self.gamma is None):
@@ -186,7 +189,7 @@ class VecExplorer(object):
                 raise ValueError("action_seq rollouts record no per-step states; use action_fn with update_memory")
             limit = min(limit, int(action_seq.shape[0]))
             while t < limit:
-                n = min(128, limit - t)                      # per launch: ~30 us fixed cost vs ~3 us per step
+                n = min(128, limit - t)                      # a launch's time is set by its slowest env group
                 env.rollout(action_seq[t:t + n])
                 t += n
                 if int(bufs["fin_count"].min().item()) >= rounds:
@@ -233,8 +236,8 @@ class VecExplorer(object):
                                  torch.stack(col_i).cpu().numpy(), k, rounds, E_total, update_raw_ob, cacheFile)
         env.case_counter[phase] = (first + k) % size
         # records in global episode order: episode g = r * E_total + global_env
-        rec = mdist.gather_records(bufs["fin_return"].t().contiguous(), bufs["fin_info"].t().contiguous(),
-                                   bufs["fin_time"].t().contiguous())
+        rec = mdist.gather_records(bufs["fin_return"][:rounds].t().contiguous(), bufs["fin_info"][:rounds].t().contiguous(),
+                                   bufs["fin_time"][:rounds].t().contiguous())
         ret = rec["return"].view(-1, rounds).cpu().numpy()        # [E_total, rounds]
         inf = rec["info"].view(-1, rounds).cpu().numpy()
         tim = rec["time"].view(-1, rounds).cpu().numpy()

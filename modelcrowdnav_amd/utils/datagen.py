@@ -354,13 +354,8 @@ class VecDataGen(object):
                 if stay:
                     act = torch.zeros(E, 2, dtype=torch.float64, device=dev)
                 else:
+                    # epsilon-greedy in phase 'train' happens inside predict_batch (multi_human_rl.py:27-29)
                     act, _ = pol.predict_batch(seen, hcount=getattr(seen, "hcount", None))
-                    eps = float(getattr(pol, "epsilon", 0) or 0)
-                    if phase == "train" and eps > 0:            # multi_human_rl.py:28-30, one draw per env
-                        table = pol._bufs["table"]
-                        explore = torch.rand(E, device=dev) < eps
-                        ridx = torch.randint(0, table.shape[0], (E,), device=dev)
-                        act = torch.where(explore.unsqueeze(1), table[ridx], act)
                 replay = (i + 1) < length                                        # :452 per env
                 nxt = obs[:, min(i + 1, T_rec - 1), :, 2:4]
                 if ragged:                                 # `[...][:self.env.human_num]`: only who is there moves (:453)
@@ -445,3 +440,12 @@ class VecDataGen(object):
         from ..policy.world_model import round4
         rows = keep.nonzero().squeeze(1)
         sim.hist[rows.view(-1, 1), order.view(1, -1)] = round4(hist0[rows].to(sim.hist.dtype))
+
+
+class DataGen(VecDataGen):
+    """The reference's name (datagen.py:20; train_model_based_sgan.py:223 `DataGen(memory, robot, env_sim, policy)`).
+    `env` may be the gym-style E = 1 ModelCrowdSim view, whose batched env is then used, or a VecModelCrowdSim."""
+
+    def __init__(self, memory, robot, env, policy):
+        vec = env.__dict__.get("_vec") if hasattr(env, "__dict__") else None
+        super().__init__(memory, robot, vec if vec is not None else env, policy)

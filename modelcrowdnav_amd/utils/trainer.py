@@ -4,7 +4,13 @@
 Data-parallel: when torch.distributed is initialised every rank trains on its own memory shard and the
 gradients are averaged with ONE all-reduce of a single flat bucket per step (96 502 floats = 386 KB: latency-
 bound on xGMI, so one message, not one per tensor).  Weights start identical (broadcast from rank 0 in
-`sync_weights`) and stay identical because every rank applies the same averaged gradient.
+`sync_weights`) and stay identical because every rank applies the same averaged gradient.  Ranks hold different
+amounts of experience (episode lengths differ per env shard), so the number of steps of an epoch is agreed on ONCE
+per epoch (all-reduce MAX of the local batch counts) and a rank that runs out of rows wraps around its own
+permutation: every rank issues the same number of collectives, every batch is full.
+
+The arithmetic (one SGD-momentum step of the MSE loss) is pinned against the reference's own Trainer by
+tests/golden/g10_trainer.npz (tests/test_training_cpu.py).
 """
 import logging
 
@@ -70,17 +76,37 @@ class Trainer(object):
         return loss.data.item()
 
     # ------------------------------------------------------------------ reference surface
-    def optimize_epoch(self, num_epochs):
-        """trainer.py:38-62: full passes over the memory in shuffled mini-batches; returns epoch_loss / len(memory)."""
+    def _agreed_steps(self, n_local):
+        """Mini-batches per epoch: the local count, or with several ranks the largest count of any rank."""
+        steps = -(-n_local // self.batch_size)
+        if self._world() > 1:
+            dev = self.device if dist.get_backend() == "nccl" else torch.device("cpu")
+            t = torch.tensor([steps], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            steps = int(t.item())
+        return steps
+
+    def optimize_epoch(self, num_epochs, perms=None):
+        """trainer.py:38-62: full passes over the memory in shuffled mini-batches; returns epoch_loss / len(memory).
+        perms (optional, [num_epochs][n] index rows) replaces the shuffles this trainer would draw itself -- the
+        reference's DataLoader draws them from torch's global generator."""
         if self.optimizer is None:
             raise ValueError("Learning rate is not set!")
         average_epoch_loss = 0
         n = len(self.memory)
-        for _ in range(num_epochs):
+        multi = self._world() > 1
+        for ep in range(num_epochs):
             epoch_loss = 0
-            perm = torch.randperm(n, generator=self._gen)
-            for lo in range(0, n, self.batch_size):
-                idx = perm[lo:lo + self.batch_size].to(self.memory._states.device)
+            perm = torch.randperm(n, generator=self._gen) if perms is None else torch.as_tensor(perms[ep], dtype=torch.long)
+            steps = self._agreed_steps(n)
+            for b in range(steps):
+                lo = b * self.batch_size
+                if multi:
+                    # every rank runs `steps` full batches; a rank with fewer rows wraps around its permutation
+                    idx = perm[(lo + torch.arange(self.batch_size)) % n]
+                else:
+                    idx = perm[lo:lo + self.batch_size]
+                idx = idx.to(self.memory._states.device)
                 epoch_loss += self._step(self.memory._states[idx].to(self.device), self.memory._values[idx].to(self.device))
             average_epoch_loss = epoch_loss / n
         return average_epoch_loss

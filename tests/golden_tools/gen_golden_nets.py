@@ -11,6 +11,8 @@
   g9_realdata GetRealData on a synthetic TrajNet++ ndjson (tests/golden/g9_scenes.ndjson, written by this tool):
               per-frame observation lists, start_ends, world-model pairs, SGAN cache files, for the default options
               and for windowed scenes with 'moving' / 'stay' padding           (misc.py:47-187, reader.py:44-166)
+  g10_trainer Trainer.optimize_batch / optimize_epoch (SGD momentum 0.9, MSE) on a seeded ValueNetwork and memory:
+              weights before / after, losses                                   (trainer.py:19-82)
   g8_datagen  DataGen.gen_data_from_explore_in_mix on a synthetic recorded set: replay-then-freeze and
               replay-then-imagine (MlpWorld) samples, memory contents in IL and RL mode
                                                                       (datagen.py:379-543)
@@ -365,4 +367,53 @@ def g6_sgan():
     print("g6_sgan: %d arrays" % len(rec))
 
 
-FAMILIES = {"g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}
+def g10_trainer():
+    """Reference Trainer (crowd_nav/utils/trainer.py:19-82) on a seeded SARL ValueNetwork and a seeded memory of
+    (state [5,13], value [1]) pairs.  optimize_batch: the memory holds exactly one batch, so every step sees all rows
+    (the DataLoader's shuffle only permutes them inside the batch); optimize_epoch: two full batches per epoch in the
+    order of the DataLoader's permutation, which is recorded."""
+    from crowd_sim.envs.utils.state import JointState  # noqa: F401  (first: the reference's packages import each other)
+    from crowd_nav.utils.trainer import Trainer
+    from crowd_nav.utils.memory import ReplayMemory
+    rec = {}
+    rng = np.random.RandomState(10)
+    for tag, n_rows, bs in (("batch", 100, 100), ("epoch", 200, 100)):
+        pol = _sarl_policy(31)
+        model = pol.get_model()
+        if tag == "batch":                  # same seed: both cases start from these weights
+            rec.update(_state_dict_arrays(model, "w0__"))
+        states = rng.normal(0, 1, (n_rows, 5, 13)).astype(np.float32)
+        values = rng.uniform(-0.5, 1.0, (n_rows, 1)).astype(np.float32)
+        mem = ReplayMemory(n_rows)
+        for s_, v_ in zip(states, values):
+            mem.push((torch.from_numpy(s_), torch.from_numpy(v_)))
+        tr = Trainer(model, mem, torch.device("cpu"), bs)
+        tr.set_learning_rate(0.01)
+        torch.manual_seed(77)
+        if tag == "batch":
+            losses = [tr.optimize_batch(1) for _ in range(3)]
+        else:
+            # the DataLoader draws one randperm per epoch from the global generator: record it
+            g_state = torch.get_rng_state()
+            losses = [tr.optimize_epoch(1) for _ in range(2)]
+            torch.set_rng_state(g_state)
+            # replay an identical DataLoader over the row indices: it consumes the generator exactly as the Trainer's
+            import torch.utils.data as tud
+
+            class _Rows(tud.Dataset):
+                def __len__(self):
+                    return n_rows
+
+                def __getitem__(self, i):
+                    return i
+            loader = tud.DataLoader(_Rows(), bs, shuffle=True)
+            perms = [np.concatenate([b.numpy() for b in loader]).astype(np.int64) for _ in range(2)]
+            rec[tag + "_perms"] = np.stack(perms)
+        rec[tag + "_states"], rec[tag + "_values"] = states, values
+        rec[tag + "_losses"] = np.array(losses, np.float64)
+        rec.update(_state_dict_arrays(model, tag + "_w1__"))
+    np.savez_compressed(os.path.join(OUT, "g10_trainer.npz"), **rec)
+    print("g10_trainer: %d arrays" % len(rec))
+
+
+FAMILIES = {"g10": g10_trainer, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}

@@ -16,6 +16,9 @@ def test_reference_import_paths_resolve():
     from crowd_nav.utils.explorer import Explorer                # noqa: F401
     from crowd_nav.utils.memory import ReplayMemory              # noqa: F401
     from crowd_nav.utils.trainer import Trainer                  # noqa: F401
+    from crowd_nav.utils.trainer_sim import Trainer_Sim          # noqa: F401   (train_model_based_sgan.py)
+    from crowd_nav.utils.datagen import DataGen                  # noqa: F401   (train_model_based_sgan.py:26)
+    from crowd_nav.utils.misc import GetRealData, StoreAction, PositiveRate      # noqa: F401   (:29, :249-269, :389)
     assert set(["sarl", "orca", "linear", "none"]) <= set(policy_factory)
     env = gym.make("CrowdSim-v0")
     assert type(env).__name__ == "CrowdSim"

@@ -95,3 +95,31 @@ def test_action_table_bitexact(golden_dir):
             assert np.array_equal(np.array(r), g["rotations_%s_%g" % (kin, vp)])
     t, s, _ = build_action_space(1.0)
     assert s[0] == 0.12885124808584156 and tuple(t[6]) == (0.11904303084504313, 0.04930923788201555)
+
+
+def test_pow_half_vs_sqrt_never_flips_the_overlap_test():
+    """crowd_sim.py:371 computes the human-human distance as (dx**2 + dy**2)**(1/2) -- CPython float pow, i.e. libm
+    pow(x, 0.5); the oracle and the kernels use the correctly rounded sqrt.  On this libm the two differ by one ulp
+    for ~0.05 % of arguments; what the env derives from it is only the sign of `dist - r_i - r_j`, and that sign is the
+    same for every argument within 2000 ulps of the touching distance of the shipped radii (exhaustive); for random
+    radii it can differ only where |dist - r_i - r_j| is itself below one ulp (a measure-zero boundary; the count is
+    only logged by the reference, crowd_sim.py:375-376)."""
+    rng = np.random.RandomState(0)
+    x = rng.uniform(0, 200, 300000)
+    a = np.array([float(v) ** (1 / 2) for v in x])
+    assert np.mean(a != np.sqrt(x)) < 2e-3 and np.max(np.abs(a - np.sqrt(x)) / np.sqrt(x)) < 2.3e-16
+    for ri, rj in [(0.3, 0.3), (0.3, 0.45), (0.5, 0.31), (0.37, 0.42)]:
+        touch = (ri + rj) ** 2
+        xs = [touch]
+        lo = hi = touch
+        for _ in range(2000):
+            lo, hi = np.nextafter(lo, 0.0), np.nextafter(hi, 10.0)
+            xs += [lo, hi]
+        for v in xs:
+            assert ((float(v) ** (1 / 2) - ri - rj) < 0) == ((np.sqrt(v) - ri - rj) < 0), (ri, rj, v)
+    r1, r2 = rng.uniform(0.3, 0.5, 200000), rng.uniform(0.3, 0.5, 200000)
+    xs = (r1 + r2) ** 2 * (1 + rng.uniform(-1e-15, 1e-15, 200000))
+    pw = np.array([float(v) ** (1 / 2) for v in xs])
+    d_pow, d_sqrt = pw - r1 - r2, np.sqrt(xs) - r1 - r2
+    flips = (d_pow < 0) != (d_sqrt < 0)
+    assert np.all(np.abs(d_sqrt[flips]) < 4.5e-16)         # only pairs within an ulp of touching can differ

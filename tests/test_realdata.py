@@ -70,3 +70,27 @@ def test_episode_tensor_feeds_datagen(golden_dir):
     assert obs.ndim == 4 and obs.shape[3] == 5 and (lengths == 7).all() and len(ids) == obs.shape[0]
     with pytest.raises(ValueError):
         RD.RealData([dict(id=0, obs=np.zeros((3, 2, 5)), present=np.array([[1, 0], [1, 1], [1, 1]], bool))], [], []).episode_tensor()
+
+
+def test_reference_named_GetRealData_fills_the_callers_containers(golden_dir, tmp_path):
+    """crowd_nav/utils/misc.py:47-116 as the model-based driver calls it (train_model_based_sgan.py:249-269):
+    `raw_memory, rawob = GetRealData(..., Store_for_world_fn=StoreAction, cacheFile=dir)`; same fixture as above."""
+    import torch
+    from modelcrowdnav_amd.utils.misc import GetRealData, StoreAction, PositiveRate, RawMemory
+    g = np.load(os.path.join(golden_dir, "g9_realdata.npz"))
+    raw, rawob = GetRealData(os.path.join(golden_dir, "g9_scenes.ndjson"), phase="test", Store_for_world_fn=StoreAction,
+                             cacheFile=str(tmp_path))
+    name = "default_test"
+    assert [len(r[0]) for r in raw.memory] == g[name + "_count"].tolist()
+    assert [bool(r[2]) for r in raw.memory] == g[name + "_done"].tolist()
+    flat = np.array([[o.px, o.py, o.vx, o.vy, o.radius] for r in raw.memory for o in r[0]])
+    assert np.array_equal(flat, g[name + "_obs"])
+    assert [tuple(p[0].shape)[0] for p in rawob.memory] == g[name + "_pair_count"].tolist()
+    assert np.array_equal(torch.cat([p[0] for p in rawob.memory]).numpy(), g[name + "_pair_cur"])
+    assert np.array_equal(torch.cat([p[1] for p in rawob.memory]).numpy(), g[name + "_pair_next"])
+    assert len(os.listdir(tmp_path)) == int(g[name + "_cache_files"])
+    m = RawMemory(3)                           # the ring semantics of memory.py:13-19
+    for v in (1.0, -1.0, 2.0, 3.0):
+        m.push((None, torch.tensor([v])))
+    assert len(m) == 3 and m.is_full() and [float(x[1]) for x in m.memory] == [3.0, -1.0, 2.0]
+    assert PositiveRate(m) == 2 / 3

@@ -63,6 +63,76 @@ def test_trainer_reduces_loss():
     assert tr.optimize_batch(3) > 0
 
 
+def _load_sd(model, g, prefix):
+    sd = {k: torch.from_numpy(g[prefix + k.replace(".", "__")].copy()) for k in model.state_dict().keys()}
+    model.load_state_dict(sd)
+
+
+@pytest.mark.parametrize("mode", ["batch", "epoch"])
+def test_trainer_steps_match_reference_trainer(mode, golden_dir):
+    """utils/trainer.py against the REAL reference Trainer (crowd_nav/utils/trainer.py:19-82; fixture
+    tests/golden/g10_trainer.npz from tests/golden_tools/gen_golden_nets.py:g10_trainer): same seeded ValueNetwork,
+    same memory rows, lr 0.01; three optimize_batch(1) calls over a one-batch memory / two optimize_epoch(1) calls over a
+    two-batch memory with the DataLoader's recorded permutations.  Weights to 1e-6, losses to 1e-6."""
+    from modelcrowdnav_amd.utils.memory import ReplayMemory
+    from modelcrowdnav_amd.utils.trainer import Trainer
+    g = np.load(os.path.join(golden_dir, "g10_trainer.npz"))
+    torch.set_num_threads(1)
+    model = _model(seed=3)
+    _load_sd(model, g, "w0__")
+    states, values = torch.from_numpy(g[mode + "_states"]), torch.from_numpy(g[mode + "_values"])
+    mem = ReplayMemory(states.shape[0])
+    mem.push_batch(states, values.reshape(-1))
+    tr = Trainer(model, mem, torch.device("cpu"), 100)
+    tr.set_learning_rate(0.01)
+    if mode == "batch":
+        losses = [tr.optimize_batch(1) for _ in range(3)]
+    else:
+        losses = [tr.optimize_epoch(1, perms=g["epoch_perms"][i:i + 1]) for i in range(2)]
+    np.testing.assert_allclose(losses, g[mode + "_losses"], rtol=0, atol=1e-6)
+    for k, v in model.state_dict().items():
+        want = g[mode + "_w1__" + k.replace(".", "__")]
+        np.testing.assert_allclose(v.numpy(), want, rtol=0, atol=1e-6, err_msg=k)
+
+
+def _dp_unequal_worker(rank, ws, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(ws), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from modelcrowdnav_amd import dist as mdist
+    from modelcrowdnav_amd.utils.memory import ReplayMemory
+    from modelcrowdnav_amd.utils.trainer import Trainer
+    mdist.init_from_env("gloo")
+    torch.set_num_threads(1)
+    model = _model(seed=0)
+    g = torch.Generator().manual_seed(11)
+    states = torch.randn(77, 5, 13, generator=g)
+    values = torch.randn(77, generator=g)
+    rows = slice(0, 32) if rank == 0 else slice(32, 77)          # 32 vs 45 rows: 2 vs 3 mini-batches of 16
+    mem = ReplayMemory(64)
+    mem.push_batch(states[rows], values[rows])
+    tr = Trainer(model, mem, torch.device("cpu"), 16)
+    tr.sync_weights()
+    tr.set_learning_rate(0.02)
+    tr.optimize_epoch(3)                                         # would hang if the ranks disagreed on the step count
+    tr.optimize_batch(2)
+    torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(out_dir, "u%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_trainer_unequal_shards(tmp_path):
+    """Ranks with different amounts of experience (32 vs 45 rows) agree on the number of steps per epoch and stay
+    in lock step (a differing count of all-reduces would deadlock: the spawn below would time out)."""
+    port = 31300 + (os.getpid() % 1500)
+    mp.spawn(_dp_unequal_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    w0 = torch.load(os.path.join(str(tmp_path), "u0.pt"), weights_only=True)
+    w1 = torch.load(os.path.join(str(tmp_path), "u1.pt"), weights_only=True)
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k
+    assert not torch.equal(w0["mlp1.0.weight"], _model(seed=0).state_dict()["mlp1.0.weight"])
+
+
 def _dp_worker(rank, ws, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(ws), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

@@ -52,6 +52,9 @@ def gather_records(returns, infos, times, counts=None):
         cols.append(counts.reshape(-1).double())
     packed = torch.stack(cols, 1).contiguous()
     rank, ws = world()
+    home = packed.device
+    if ws > 1 and dist.get_backend() == "gloo" and packed.is_cuda:
+        packed = packed.cpu()          # rehearsals / tests on one GPU: the collective runs on host copies
     if ws == 1:
         out = packed
     else:
@@ -72,6 +75,7 @@ def gather_records(returns, infos, times, counts=None):
             bufs = [torch.empty_like(pad) for _ in range(ws)]
             dist.all_gather(bufs, pad)
             out = torch.cat([b[:int(s.item())] for b, s in zip(bufs, all_sizes)], 0)
+    out = out.to(home)
     res = {"return": out[:, 0], "info": out[:, 1].to(torch.uint8), "time": out[:, 2]}
     if counts is not None:
         res["count"] = out[:, 3].to(torch.int32)

@@ -126,6 +126,67 @@ def test_crowdsim_e1_with_orca_robot_matches_oracle():
         assert len(env.states) == steps
 
 
+def test_get_human_times_matches_oracle_simulation():
+    """crowd_sim.py:219-258: after the robot has arrived, one centralised all-ORCA simulation to the end (robot = agent
+    0, humans after it, everybody at their own radius / v_pref, pref velocity normalised beyond 1 m, float32 positions
+    advanced inside the simulator) -- one mcn_orca_batch launch per step -- against the same loop driven by the C
+    oracle's solver.  First-arrival times, final positions and the appended states must agree exactly."""
+    import torch
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.envs import CrowdSim
+    from modelcrowdnav_amd.envs.utils.robot import Robot
+    from modelcrowdnav_amd.envs.policy.policy_factory import policy_factory
+    cfg = configs.env_config()
+    env = CrowdSim()
+    env.configure(cfg)
+    robot = Robot(cfg, "robot")
+    pol = policy_factory["orca"]()
+    pol.configure(cfg)
+    robot.set_policy(pol)
+    env.set_robot(robot)
+    pol.set_phase("test"); pol.set_device(torch.device("cuda", 0)); pol.set_env(env)
+    env.reset("test", 7)
+    with pytest.raises(ValueError):
+        env.get_human_times()                       # 'Episode is not done yet'
+    for _ in range(6):                              # a few real steps so that velocities are not all zero
+        env.step(robot.act([h.get_observable_state() for h in env.humans]))
+    robot.set_position(robot.get_goal_position())   # the robot has arrived
+    agents = [robot] + env.humans
+    f32 = np.float32
+    pos = np.array([a.get_position() for a in agents]).astype(f32)
+    vel = np.array([a.get_velocity() for a in agents]).astype(f32)
+    pos64 = np.array([a.get_position() for a in agents], np.float64)       # what the agents' own fields hold
+    goal = np.array([a.get_goal_position() for a in agents], np.float64)
+    rad = np.array([a.radius for a in agents]).astype(f32)
+    vmax = np.array([a.v_pref for a in agents]).astype(f32)
+    times, t, n_states = list(env.human_times), env.global_time, len(env.states)
+    want_states = 0
+    while not all(times):
+        pref = goal - pos64
+        for i in range(len(agents)):
+            nrm = np.linalg.norm(pref[i])
+            if nrm > 1:
+                pref[i] /= np.linalg.norm(pref[i])
+        new = np.zeros_like(vel)
+        for i in range(len(agents)):
+            oth = [j for j in range(len(agents)) if j != i]
+            new[i] = cport.orca_agent(pos[i], vel[i], rad[i], vmax[i], pref[i].astype(f32), pos[oth], vel[oth], rad[oth],
+                                      neighbor_dist=10.0, max_neighbors=10, time_horizon=5.0, time_step=0.25)
+        vel = new.astype(f32)
+        pos = (pos + vel * f32(0.25)).astype(f32)
+        t += 0.25
+        for i in range(1, len(agents)):
+            if times[i - 1] == 0 and np.linalg.norm(pos64[i] - goal[i]) < agents[i].radius:
+                times[i - 1] = t
+        pos64 = pos.astype(np.float64)
+        want_states += 1
+        assert want_states < 4000
+    got = env.get_human_times()
+    assert got == times and all(x > 0 for x in got)
+    assert env.global_time == t and len(env.states) == n_states + want_states
+    assert [h.get_position() for h in env.humans] == [tuple(p) for p in pos64[1:].tolist()]
+
+
 def test_crowdsim_e1_sarl_episode_matches_reference(golden_dir):
     """G7: reference CrowdSim + SARL (seeded weights) episodes; this build's CrowdSim + SARL must take the same
     actions and collect the same rewards step by step."""

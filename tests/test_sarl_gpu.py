@@ -94,6 +94,46 @@ def test_predict_batch_matches_oracle(N):
             assert best[e] == idx and tuple(actions[e]) == tuple(table[idx])
 
 
+def test_epsilon_greedy_in_train_phase():
+    """multi_human_rl.py:27-29 per env: phase 'train' with epsilon = 1 replaces every choice by a uniformly drawn
+    table action (except robots already on their goal, which return before the draw), epsilon = 0 is the greedy
+    choice, and test phase ignores epsilon.  VecExplorer's training rollouts go through the same call."""
+    import torch
+    rng = np.random.RandomState(12)
+    E, N = 2048, 5
+    pol = _policy(seed=3)
+    env = H.make_vec_env(E, N)
+    st = H.random_state(rng, E, N)
+    st.rgx[0], st.rgy[0] = st.rpx[0] + 0.05, st.rpy[0] - 0.05        # env 0: robot already at its goal
+    H.upload(env, st)
+    greedy_a, greedy_b = pol.predict_batch(env)
+    pol.set_epsilon(1.0)
+    a_test, b_test = pol.predict_batch(env)                          # phase 'test': epsilon is not looked at
+    assert torch.equal(b_test, greedy_b) and torch.equal(a_test, greedy_a)
+    pol.set_phase("train")
+    torch.manual_seed(5)
+    a1, b1 = pol.predict_batch(env)
+    assert int(b1[0]) == -1 and tuple(a1[0].tolist()) == (0.0, 0.0)
+    moving = greedy_b >= 0
+    assert bool((b1[moving] == -2).all())
+    table = pol._bufs["table"]
+    # every explored action is a table row, and the draw is spread over the table
+    match = (a1[moving].unsqueeze(1) == table.unsqueeze(0)).all(2)
+    assert bool(match.any(1).all())
+    counts = match.float().sum(0)
+    assert int((counts > 0).sum()) >= 75 and float(counts.max()) < 0.05 * float(moving.sum())
+    assert float((a1[moving] != greedy_a[moving]).any(1).float().mean()) > 0.9
+    pol.set_epsilon(0.25)
+    a2, b2 = pol.predict_batch(env)
+    frac = float((b2[moving] == -2).float().mean())
+    assert 0.2 < frac < 0.3
+    keep = moving & (b2 != -2)
+    assert torch.equal(a2[keep], greedy_a[keep]) and torch.equal(b2[keep], greedy_b[keep])
+    pol.set_epsilon(0.0)
+    a3, b3 = pol.predict_batch(env)
+    assert torch.equal(b3, greedy_b) and torch.equal(a3, greedy_a)
+
+
 def test_rewards_are_float64_exact():
     """With a zeroed network V == 0, so values are exactly MultiHumanRL.compute_reward (float64)."""
     import torch

@@ -295,7 +295,7 @@ typedef struct mcn_tuning {
     int32_t quad_split;      /* quad kernel: ORCA and float64 pairwise work on two cooperating wavefronts (0/1) */
     int32_t rollout_fused;   /* mcn_env_rollout: one T-step launch (1) or T single-step launches (0) */
     int32_t rollout_split;   /* fused rollout: two cooperating wavefronts per env group (0/1) */
-    int32_t rollout_octet;   /* reserved for the many-lanes-per-human forms (-1 / 0 / 1) */
+    int32_t reserved;        /* -1 */
     int32_t diag_noop;       /* DIAGNOSTIC build only (make stamp): env kernels return at entry; MCN_EINVAL otherwise */
     int32_t pair_stream;     /* given-velocity step: streaming kernel (env_pair.hip) 1 wherever it applies / 0 never */
 } mcn_tuning;

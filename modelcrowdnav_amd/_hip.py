@@ -92,7 +92,7 @@ RULE_CIRCLE, RULE_SQUARE = 0, 1
 class Tuning(C.Structure):
     """mcn_tuning: dispatch overrides, -1 = automatic."""
     _fields_ = [(k, _i) for k in ("force_generic", "quad_max_envs", "quad_split", "rollout_fused", "rollout_split",
-                                  "rollout_octet", "diag_noop", "pair_stream")]
+                                  "reserved", "diag_noop", "pair_stream")]
 
 
 class McnError(RuntimeError):
@@ -161,7 +161,7 @@ def set_tuning(**kw):
         check(lib.mcn_set_tuning(None), "mcn_set_tuning")
         return prev
     t = Tuning(force_generic=0, quad_max_envs=-1, quad_split=-1, rollout_fused=-1, rollout_split=-1,
-               rollout_octet=-1, diag_noop=0, pair_stream=-1)
+               reserved=-1, diag_noop=0, pair_stream=-1)
     for k, v in kw.items():
         if k not in dict(Tuning._fields_):
             raise TypeError("unknown tuning field %r" % k)

@@ -48,7 +48,7 @@ static mcn_tuning tuning_from_env()
     t.quad_split = env_or("MCN_QUAD_SPLIT", -1);
     t.rollout_fused = env_or("MCN_ROLLOUT_FUSED", -1);
     t.rollout_split = env_or("MCN_ROLLOUT_SPLIT", -1);
-    t.rollout_octet = env_or("MCN_ROLLOUT_OCTET", -1);
+    t.reserved = -1;
     t.pair_stream = env_or("MCN_PAIR_STREAM", -1);
     return t;
 }

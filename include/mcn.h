@@ -245,6 +245,20 @@ int mcn_sarl_lookahead(const mcn_sarl_net *net, const mcn_env_state *st, const d
                        double *values, int32_t *best, double *best_val, float *attention,
                        int32_t E, int32_t N, void *stream);
 
+/*
+ * mcn_sarl_lookahead_env -- the same look-ahead with `query_env = true` (multi_human_rl.py:37-38, cadrl.py:158-159):
+ * the humans' next states and the per-action rewards are what the env's own one-step look-ahead returned
+ * (CrowdSim.onestep_lookahead, crowd_sim.py:325-329) instead of constant-velocity propagation + compute_reward.
+ * next_hpos / next_hvel: [E*N][2] -- out->nobs_pos / nobs_vel of one mcn_env_step(update = 0) (the humans' reaction
+ * does not depend on the candidate action: they see the robot's current state, crowd_sim.py:336-342);
+ * rewards: [E][A] -- reward of mcn_env_step for every (env, action).  Everything else as mcn_sarl_lookahead.
+ */
+int mcn_sarl_lookahead_env(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int32_t A,
+                           double time_step, double gamma_pow, int32_t kinematics, void *workspace,
+                           double *values, int32_t *best, double *best_val, float *attention,
+                           const double *next_hpos, const double *next_hvel, const double *rewards,
+                           int32_t E, int32_t N, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Social-GAN one-step world model (crowd_nav/policy/world_model.py:134-268, sgan/models.py:501-553).
  * ---------------------------------------------------------------------------------------------- */

@@ -17,7 +17,8 @@ struct SarlParams;
 long sarl_workspace_float4s(int E, int N, int A);
 int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int A, double dt,
                   double gamma_pow, int kinematics, void *workspace, double *values, int32_t *best, double *best_val,
-                  float *attention, int E, int N, hipStream_t stream);
+                  float *attention, const double *next_hpos, const double *next_hvel, const double *reward_in,
+                  int E, int N, hipStream_t stream);
 int launch_sgan(const mcn_sgan_net *net, double *hist, int push_slot, int oldest, const double *cur_pos,
                 const float *noise, const int32_t *hcount, void *workspace, double *out_vel, float *out_rel,
                 double time_step, int E, int N, hipStream_t stream);
@@ -235,22 +236,44 @@ int64_t mcn_sarl_workspace_bytes(int32_t E, int32_t N, int32_t A)
     return (int64_t)mcn::sarl_workspace_float4s(E, N, A) * 16;
 }
 
-int mcn_sarl_lookahead(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int32_t A,
-                       double time_step, double gamma_pow, int32_t kinematics, void *workspace,
-                       double *values, int32_t *best, double *best_val, float *attention,
-                       int32_t E, int32_t N, void *stream)
+static int sarl_lookahead_impl(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int32_t A,
+                               double time_step, double gamma_pow, int32_t kinematics, void *workspace,
+                               double *values, int32_t *best, double *best_val, float *attention,
+                               const double *next_hpos, const double *next_hvel, const double *rewards,
+                               int32_t E, int32_t N, void *stream)
 {
     if (!net || !st || !actions || !workspace || !values) return MCN_EINVAL;
     if (E <= 0 || N <= 0 || N > MCN_MAX_HUMANS || A <= 0) return MCN_EINVAL;
     if (best && !best_val) return MCN_EINVAL;
     if (!st->hpos || !st->hvel || !st->hrad || !st->rpos || !st->rgoal || !st->rrad || !st->rvpref) return MCN_EINVAL;
     if (kinematics == MCN_KIN_UNICYCLE && !st->rtheta) return MCN_EINVAL;
+    if ((next_hpos == nullptr) != (next_hvel == nullptr)) return MCN_EINVAL;
     const float *const *fp = reinterpret_cast<const float *const *>(net);
     for (size_t k = 0; k < sizeof(mcn_sarl_net) / sizeof(float *); ++k)
         if (!fp[k]) return MCN_EINVAL;
     if (!(time_step > 0)) return MCN_EINVAL;
     return mcn::launch_sarl_c(net, st, actions, A, time_step, gamma_pow, kinematics, workspace, values, best,
-                              best_val, attention, E, N, (hipStream_t)stream);
+                              best_val, attention, next_hpos, next_hvel, rewards, E, N, (hipStream_t)stream);
+}
+
+int mcn_sarl_lookahead(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int32_t A,
+                       double time_step, double gamma_pow, int32_t kinematics, void *workspace,
+                       double *values, int32_t *best, double *best_val, float *attention,
+                       int32_t E, int32_t N, void *stream)
+{
+    return sarl_lookahead_impl(net, st, actions, A, time_step, gamma_pow, kinematics, workspace, values, best, best_val,
+                               attention, nullptr, nullptr, nullptr, E, N, stream);
+}
+
+int mcn_sarl_lookahead_env(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int32_t A,
+                           double time_step, double gamma_pow, int32_t kinematics, void *workspace,
+                           double *values, int32_t *best, double *best_val, float *attention,
+                           const double *next_hpos, const double *next_hvel, const double *rewards,
+                           int32_t E, int32_t N, void *stream)
+{
+    if (!next_hpos || !next_hvel || !rewards) return MCN_EINVAL;
+    return sarl_lookahead_impl(net, st, actions, A, time_step, gamma_pow, kinematics, workspace, values, best, best_val,
+                               attention, next_hpos, next_hvel, rewards, E, N, stream);
 }
 
 int64_t mcn_sgan_workspace_bytes(int32_t E, int32_t N)

@@ -63,6 +63,10 @@ struct SarlParams {
     const double *rpos, *rvel, *rgoal, *rrad, *rvpref, *rtheta;   // [E][2] / [E]
     const double *hpos, *hvel, *hrad;                             // [E*N][2] / [E*N]
     const int32_t *hcount;                                        // [E] or NULL: humans the policy sees
+    // query_env = true (multi_human_rl.py:37-38): the humans' next states and the rewards come from the env's own
+    // one-step look-ahead instead of constant-velocity propagation + compute_reward; all three NULL otherwise
+    const double *next_hpos, *next_hvel;                          // [E*N][2]
+    const double *reward_in;                                      // [E*A]
     const double *actions;                                // [A][2]
     float4 *workspace;                                    // [waves][N][T100][64] float4
     double *values;                                       // [E*A]
@@ -136,10 +140,16 @@ __global__ __launch_bounds__(kSarlWaves * 64, 2) void sarl_value_kernel(const Sa
         const double2 hp = reinterpret_cast<const double2 *>(p.hpos)[ha];
         const double2 hv = reinterpret_cast<const double2 *>(p.hvel)[ha];
         const double hr = p.hrad[ha];
-        const double qx = hp.x + hv.x * dt, qy = hp.y + hv.y * dt;      // constant-velocity propagate
+        double qx = hp.x + hv.x * dt, qy = hp.y + hv.y * dt;            // constant-velocity propagate
+        double nhvx = hv.x, nhvy = hv.y;
+        if (p.next_hpos) {                                              // the env's look-ahead states instead
+            const double2 np_ = reinterpret_cast<const double2 *>(p.next_hpos)[ha];
+            const double2 nv_ = reinterpret_cast<const double2 *>(p.next_hvel)[ha];
+            qx = np_.x; qy = np_.y; nhvx = nv_.x; nhvy = nv_.y;
+        }
         const double d = norm2d(npx - qx, npy - qy) - ra.x - hr;        // multi_human_rl.py:70
         dmin = i < ne ? fmin(dmin, d) : dmin;
-        const float hx = (float)qx, hy = (float)qy, hvx = (float)hv.x, hvy = (float)hv.y, hrad = (float)hr;
+        const float hx = (float)qx, hy = (float)qy, hvx = (float)nhvx, hvy = (float)nhvy, hrad = (float)hr;
         const float ox = hx - spx, oy = hy - spy;
         float feat[16];
         feat[0] = dg; feat[1] = svpref; feat[2] = f_theta; feat[3] = srad; feat[4] = f_vx; feat[5] = f_vy;
@@ -172,6 +182,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, 2) void sarl_value_kernel(const Sa
     else if (reach) reward = 1;
     else if (dmin < 0.2) reward = (dmin - 0.2) * 0.5 * dt;
     else reward = 0;
+    if (p.reward_in) reward = p.reward_in[pair];
 
     // global state = mean over humans (sarl.py:41); its contribution to attention layer 0 is the same for
     // every human of the pair, so it becomes the accumulator init of that layer
@@ -290,7 +301,8 @@ int launch_sarl(const SarlParams &p, int32_t *best, double *best_val, hipStream_
 
 int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int A, double dt,
                   double gamma_pow, int kinematics, void *workspace, double *values, int32_t *best, double *best_val,
-                  float *attention, int E, int N, hipStream_t stream)
+                  float *attention, const double *next_hpos, const double *next_hvel, const double *reward_in,
+                  int E, int N, hipStream_t stream)
 {
     SarlParams p;
     const float4 *const *src = reinterpret_cast<const float4 *const *>(net);
@@ -299,6 +311,7 @@ int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double
     for (size_t k = 0; k < sizeof(mcn_sarl_net) / sizeof(float *); ++k) dst[k] = src[k];
     p.rpos = st->rpos; p.rvel = st->rvel; p.rgoal = st->rgoal; p.rrad = st->rrad; p.rvpref = st->rvpref; p.rtheta = st->rtheta;
     p.hpos = st->hpos; p.hvel = st->hvel; p.hrad = st->hrad; p.hcount = st->hcount;
+    p.next_hpos = next_hpos; p.next_hvel = next_hvel; p.reward_in = reward_in;
     p.actions = actions; p.workspace = reinterpret_cast<float4 *>(workspace);
     p.values = values; p.attention = attention;
     p.E = E; p.N = N; p.A = A; p.kinematics = kinematics; p.dt = dt; p.gamma_pow = gamma_pow;

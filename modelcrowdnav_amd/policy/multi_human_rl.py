@@ -36,8 +36,10 @@ class MultiHumanRL(CADRL):
     def _packed(self, dev):
         raise NotImplementedError
 
-    def _lookahead(self, st, E, N, dev, want_attention=False):
-        """Launch mcn_sarl_lookahead on an EnvState struct; returns (values[E,A], best[E], best_val[E], att)."""
+    def _lookahead(self, st, E, N, dev, want_attention=False, env_next=None):
+        """Launch mcn_sarl_lookahead on an EnvState struct; returns (values[E,A], best[E], best_val[E], att).
+        env_next = (next_hpos [E,N,2], next_hvel [E,N,2], rewards [E,A]): the `query_env` form
+        (mcn_sarl_lookahead_env) -- the env's look-ahead states and rewards instead of propagate + compute_reward."""
         if self.action_space is None:
             raise RuntimeError("action space not built")
         A = len(self.action_space)
@@ -59,12 +61,51 @@ class MultiHumanRL(CADRL):
         net = self._packed(dev)
         kin = _hip.KIN_UNICYCLE if self.kinematics == "unicycle" else _hip.KIN_HOLONOMIC
         gamma_pow = pow(self.gamma, self.time_step * self._v_pref)       # multi_human_rl.py:52
-        rc = _hip.lib.mcn_sarl_lookahead(C.byref(net), st, _hip.ptr(b["table"]), A, float(self.time_step), gamma_pow, kin,
-                                         _hip.ptr(b["ws"]), _hip.ptr(b["values"]), _hip.ptr(b["best"]),
-                                         _hip.ptr(b["best_val"]), _hip.ptr(b["att"]) if want_attention else None,
-                                         E, N, _hip.stream_ptr(dev))
+        if env_next is None:
+            rc = _hip.lib.mcn_sarl_lookahead(C.byref(net), st, _hip.ptr(b["table"]), A, float(self.time_step), gamma_pow, kin,
+                                             _hip.ptr(b["ws"]), _hip.ptr(b["values"]), _hip.ptr(b["best"]),
+                                             _hip.ptr(b["best_val"]), _hip.ptr(b["att"]) if want_attention else None,
+                                             E, N, _hip.stream_ptr(dev))
+        else:
+            npos, nvel, rew = env_next
+            rc = _hip.lib.mcn_sarl_lookahead_env(C.byref(net), st, _hip.ptr(b["table"]), A, float(self.time_step), gamma_pow,
+                                                 kin, _hip.ptr(b["ws"]), _hip.ptr(b["values"]), _hip.ptr(b["best"]),
+                                                 _hip.ptr(b["best_val"]), _hip.ptr(b["att"]) if want_attention else None,
+                                                 _hip.ptr(npos), _hip.ptr(nvel), _hip.ptr(rew), E, N, _hip.stream_ptr(dev))
         _hip.check(rc, "mcn_sarl_lookahead")
         return b["values"], b["best"], b["best_val"], b["att"]
+
+    def _query_env(self, venv):
+        """`query_env = true` (multi_human_rl.py:37-38): what `env.onestep_lookahead(action)` returns for every action
+        of the table, for all E envs of the batched env `venv`.  The humans react to the robot's CURRENT state
+        (crowd_sim.py:336-342), so their next states do not depend on the candidate action: ONE mcn_env_step(update = 0)
+        gives them; the reward (swept-circle test against the candidate action, goal test, time limit) does, and comes
+        from one given-velocity mcn_env_step over the E x A (env, action) pairs on a scratch copy of the state.
+        Returns (next_hpos [E,N,2], next_hvel [E,N,2], rewards [E,A])."""
+        E, N, dev = venv.num_envs, venv._alloc_N, venv.device
+        A = len(self.action_space)
+        table = self._bufs["table"] if self._bufs.get("table") is not None else \
+            torch.from_numpy(np.ascontiguousarray(self._action_table)).to(dev)
+        ob, _, _, _ = venv.onestep_lookahead(torch.zeros(E, 2, dtype=torch.float64, device=dev))
+        npos, nvel = ob.pos.clone(), ob.vel.clone()
+        rep = lambda t: t.repeat_interleave(A, 0).contiguous()
+        x = dict(hpos=rep(venv.hpos), hvel=rep(venv.hvel), hrad=rep(venv.hrad), rpos=rep(venv.rpos), rvel=rep(venv.rvel),
+                 rgoal=rep(venv.rgoal), rrad=rep(venv.rrad), rvpref=rep(venv.rvpref), rtheta=rep(venv.rtheta),
+                 gtime=rep(venv.gtime))
+        st = _hip.EnvState()
+        for k, v in x.items():
+            setattr(st, k, _hip.ptr(v))
+        st.hgoal, st.hvpref = _hip.ptr(x["hpos"]), _hip.ptr(x["hrad"])      # not read with given velocities
+        acts = table.repeat(E, 1).contiguous()
+        given = rep(nvel)
+        rec = torch.zeros(E * A, 3, dtype=torch.float64, device=dev)
+        out = _hip.EnvOut(_hip.ptr(rec), None, None, None)
+        cfg = venv._cfg_struct("given")
+        cfg.count_hh = 0
+        cfg.track_human_times = 0
+        _hip.check(_hip.lib.mcn_env_step(cfg, st, _hip.ptr(acts), _hip.ptr(given), out, None, E * A, N, 1,
+                                         _hip.stream_ptr(dev)), "mcn_env_step")
+        return npos, nvel, rec[:, 0].reshape(E, A).contiguous()
 
     # ------------------------------------------------------------------ reference surface (E = 1)
     def predict(self, state):
@@ -80,9 +121,6 @@ class MultiHumanRL(CADRL):
             self.build_action_space(me.v_pref)
         if self.with_om:
             raise NotImplementedError("occupancy maps (with_om) are outside this build's scope")
-        if self.query_env:
-            raise NotImplementedError("query_env=true (81 full env steps per decision) is not built; "
-                                      "the shipped policy.config uses query_env=false")
         probability = np.random.random()                       # drawn unconditionally, as the reference does
         if self.phase == "train" and probability < self.epsilon:
             max_action = self.action_space[np.random.choice(len(self.action_space))]
@@ -99,7 +137,16 @@ class MultiHumanRL(CADRL):
             for k, v in bufs.items():
                 setattr(st, k, _hip.ptr(v))
             self._v_pref = me.v_pref
-            values, best, _, att = self._lookahead(st, 1, N, dev, want_attention=True)
+            env_next = None
+            if self.query_env:
+                # the reference asks its env (whose internal state is the current one) 81 times; here the E = 1 view's
+                # batched env answers for the whole table at once
+                venv = self.env.__dict__.get("_vec") if hasattr(self.env, "__dict__") else None
+                if venv is None:
+                    raise AttributeError("query_env needs set_env(CrowdSim)")
+                self.env._push_host_state()
+                env_next = self._query_env(venv)
+            values, best, _, att = self._lookahead(st, 1, N, dev, want_attention=True, env_next=env_next)
             vals = values[0].cpu().numpy()
             self.action_values = vals.tolist()
             idx = int(best.item())
@@ -153,7 +200,14 @@ class MultiHumanRL(CADRL):
                 raise ValueError("hcount must be a contiguous int32 tensor with one entry per env")
             st = _hip.EnvState.from_buffer_copy(env._st)
             st.hcount = _hip.ptr(hcount)
-        values, best, best_val, _ = self._lookahead(st, env.num_envs, env._alloc_N, dev)
+        env_next = None
+        if self.query_env:
+            if hcount is not None:
+                raise NotImplementedError("query_env with per-env pedestrian counts")
+            if self._bufs.get("table") is None:
+                self._bufs["table"] = torch.from_numpy(np.ascontiguousarray(self._action_table)).to(dev)
+            env_next = self._query_env(env)
+        values, best, best_val, _ = self._lookahead(st, env.num_envs, env._alloc_N, dev, env_next=env_next)
         table = self._bufs["table"]
         eps = float(getattr(self, "epsilon", 0) or 0)
         if self.phase == "train" and eps > 0:

@@ -11,6 +11,8 @@
   g9_realdata GetRealData on a synthetic TrajNet++ ndjson (tests/golden/g9_scenes.ndjson, written by this tool):
               per-frame observation lists, start_ends, world-model pairs, SGAN cache files, for the default options
               and for windowed scenes with 'moving' / 'stay' padding           (misc.py:47-187, reader.py:44-166)
+  g11_queryenv SARL with query_env = true driving the reference CrowdSim: per-step action values through
+              env.onestep_lookahead                                            (multi_human_rl.py:35-55, crowd_sim.py:325-329)
   g10_trainer Trainer.optimize_batch / optimize_epoch (SGD momentum 0.9, MSE) on a seeded ValueNetwork and memory:
               weights before / after, losses                                   (trainer.py:19-82)
   g8_datagen  DataGen.gen_data_from_explore_in_mix on a synthetic recorded set: replay-then-freeze and
@@ -367,6 +369,38 @@ def g6_sgan():
     print("g6_sgan: %d arrays" % len(rec))
 
 
+def g11_queryenv():
+    """Reference CrowdSim (ORCA humans through the rvo2 stand-in) + SARL robot with `query_env = true`
+    (multi_human_rl.py:37-38: every candidate action is evaluated through env.onestep_lookahead): episodes with an
+    invisible and with a visible robot; per step the chosen action, the 81 action values, reward, info."""
+    rec = {}
+    for vis in (False, True):
+        torch.manual_seed(2)
+        env, robot, pol = G.make_env("CrowdSim", robot_policy="sarl", humans_policy="orca", human_num=5, robot_visible=vis)
+        pol.query_env = True
+        pol.set_env(env)
+        tag = "vis%d_" % int(vis)
+        if not vis:                          # same seed: one set of weights
+            rec.update(_state_dict_arrays(pol.model, "w__"))
+        for case in (0, 5):
+            ob = env.reset("test", case)
+            done, t = False, 0
+            A, V, R, I = [], [], [], []
+            while not done and t < 25:
+                with torch.no_grad():
+                    action = robot.act(ob)
+                V.append(np.array(pol.action_values, np.float64))
+                ob, reward, done, info = env.step(action)
+                A.append([action.vx, action.vy]); R.append(reward); I.append(G.info_code(info))
+                t += 1
+            key = tag + "c%d_" % case
+            rec[key + "actions"] = np.array(A); rec[key + "values"] = np.array(V)
+            rec[key + "rewards"] = np.array(R); rec[key + "info"] = np.array(I)
+            print("  query_env visible %d case %d: %d steps, outcome %d" % (vis, case, t, I[-1]))
+    np.savez_compressed(os.path.join(OUT, "g11_queryenv.npz"), **rec)
+    print("g11_queryenv: %d arrays" % len(rec))
+
+
 def g10_trainer():
     """Reference Trainer (crowd_nav/utils/trainer.py:19-82) on a seeded SARL ValueNetwork and a seeded memory of
     (state [5,13], value [1]) pairs.  optimize_batch: the memory holds exactly one batch, so every step sees all rows
@@ -416,4 +450,4 @@ def g10_trainer():
     print("g10_trainer: %d arrays" % len(rec))
 
 
-FAMILIES = {"g10": g10_trainer, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}
+FAMILIES = {"g10": g10_trainer, "g11": g11_queryenv, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}

@@ -228,6 +228,70 @@ def test_crowdsim_e1_sarl_episode_matches_reference(golden_dir):
             assert env.global_time == float(g[key + "time"])
 
 
+@pytest.mark.parametrize("visible", [False, True])
+def test_query_env_lookahead_matches_reference(visible, golden_dir):
+    """G11: `query_env = true` (multi_human_rl.py:37-38, cadrl.py:158-159).  The reference evaluates each of the 81
+    candidate actions through env.onestep_lookahead; here one mcn_env_step(update = 0) supplies the humans' reaction, one
+    given-velocity mcn_env_step over the 81 (env, action) pairs the rewards, and mcn_sarl_lookahead_env the values.
+    Per step: the 81 action values to 1e-5, the chosen action, reward and info -- with an invisible and a visible robot;
+    plus the batched form over several envs against the E = 1 path."""
+    import torch
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.envs import CrowdSim
+    from modelcrowdnav_amd.envs.utils.robot import Robot
+    from modelcrowdnav_amd.policy.policy_factory import policy_factory
+    g = np.load(os.path.join(golden_dir, "g11_queryenv.npz"))
+    cfg = configs.env_config(**{"robot.visible": "true" if visible else "false"})
+    env = CrowdSim()
+    env.configure(cfg)
+    robot = Robot(cfg, "robot")
+    pol = policy_factory["sarl"]()
+    pol.configure(configs.policy_config())
+    pol.kinematics = "holonomic"
+    pol.model.load_state_dict({k[3:].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith("w__")})
+    robot.set_policy(pol)
+    env.set_robot(robot)
+    pol.set_phase("test"); pol.set_device(torch.device("cuda", 0)); pol.set_env(env)
+    pol.query_env = True
+    for case in (0, 5):
+        key = "vis%d_c%d_" % (int(visible), case)
+        ob = env.reset("test", case)
+        for t in range(len(g[key + "rewards"])):
+            action = robot.act(ob)
+            want_v = g[key + "values"][t]
+            np.testing.assert_allclose(np.array(pol.action_values), want_v, rtol=0, atol=1e-5, err_msg="%s step %d" % (key, t))
+            top2 = np.sort(want_v)[-2:]
+            if top2[1] - top2[0] > 2e-5:
+                assert (action.vx, action.vy) == tuple(g[key + "actions"][t]), (key, t)
+            # follow the reference's trajectory even where a near-tie was broken differently
+            from modelcrowdnav_amd.envs.utils.action import ActionXY
+            ob, reward, done, info = env.step(ActionXY(*g[key + "actions"][t]))
+            assert reward == g[key + "rewards"][t] and info.code == g[key + "info"][t], (key, t)
+    # batched: predict_batch(query_env) over a VecCrowdSim in the states of several test cases == the E = 1 path
+    from tests import helpers as H
+    E = 6
+    venv = H.make_vec_env(E, 5, robot_visible=visible)
+    venv.reset("test", test_cases=[3, 4, 5, 6, 7, 8])
+    venv.robot.policy = pol                     # (only v_pref / visibility are read from the robot)
+    rng = np.random.RandomState(4)
+    for _ in range(5):                           # move off the initial layout
+        venv.step(torch.from_numpy(rng.uniform(-0.5, 0.5, (E, 2))).to(venv.device))
+    _, best, values = pol.predict_batch(venv, want_values=True)
+    best, values = best.clone(), values.clone()                     # (the policy reuses its output buffers)
+    pol.query_env = False
+    _, _, values_cv = pol.predict_batch(venv, want_values=True)
+    values_cv = values_cv.clone()
+    pol.query_env = True
+    assert float((values - values_cv).abs().max()) > 1e-6          # the two look-aheads really differ
+    for e in range(E):
+        single = H.make_vec_env(1, 5, robot_visible=visible)
+        single.load_scenarios(np.zeros((1, 5, 9)))
+        for name in ("hpos", "hvel", "hgoal", "hrad", "hvpref", "rpos", "rvel", "rgoal", "rrad", "rvpref", "rtheta", "gtime"):
+            getattr(single, name).copy_(getattr(venv, name)[e:e + 1])
+        _, b1, v1 = pol.predict_batch(single, want_values=True)
+        assert torch.equal(v1[0], values[e]) and int(b1[0]) == int(best[e])
+
+
 def test_model_crowd_sim_with_sgan_world(golden_dir):
     """BASELINE config 4 shape (reduced E): VecModelCrowdSim + VecSGANWorld + SARL robot; the env must move the
     humans exactly by the world model's velocities, and the E = 1 ModelCrowdSim view must agree with env 0."""

@@ -17,7 +17,7 @@ import bench  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--humans", type=int, default=5)
+    ap.add_argument("--humans", type=str, default="5", help="humans per env (a comma list with --sarl)")
     ap.add_argument("--sizes", default="4096,65536,1048576")
     ap.add_argument("--modes", default="orca,given")
     ap.add_argument("--visible", action="store_true")
@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--sarl", action="store_true")
     ap.add_argument("--rollout", type=int, default=0, help="time mcn_env_rollout with this many steps per launch")
     a = ap.parse_args()
+    if not a.sarl:
+        a.humans = int(a.humans)
     if a.rollout:
         rollout_bench(a)
         return

@@ -529,8 +529,12 @@ def main():
             gv = torch.rand(Es, N, 2, dtype=torch.float64, device=device) - 0.5
             env_s.count_hh = False          # ModelCrowdSim.step has no human-human check (model_crowd_sim.py:347-441)
             g_ms, _ = time_kernel_events(env_s, a_s, 50, given_v=gv)
+            # the Explorer record (32 B read + 32 B written per env-step) is real traffic the SURVEY 8(d) figure leaves out
+            rec_gbs = (pairwise_bytes_per_env_step(N) + 64) * Es / (g_ms * 1e-3) / 1e9
             sweep.append(roofline_entry(Es, N, g_ms, {"mode": "pairwise + reward + integrate (given velocities, "
                                                               "ModelCrowdSim.step)",
+                                                       "achieved_incl_explorer_record": round(rec_gbs, 2),
+                                                       "frac_incl_explorer_record": round(rec_gbs / HBM_PEAK_GBS, 5),
                                                        "env_steps_per_sec": round(Es / (g_ms * 1e-3), 1),
                                                        "roofline_valu": valu_roofline(Es, N, g_ms, 1, rollout=False, given=True)},
                                         given=True))

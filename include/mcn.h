@@ -80,6 +80,8 @@ typedef struct mcn_env_state {
 
 /* What one env reports per step, as ONE 24-byte record: the kernel issues one store per env instead of five
  * scattered 1..8-byte ones (at a million envs the narrow per-env streams, not the bytes, limit the kernel). */
+/* Alignment: 8 bytes (24-byte stride); the first 16 bytes are written with one 16-byte store, which gfx950 global
+ * memory accepts at 8-byte alignment. */
 typedef struct mcn_step_rec {
     double  reward;
     double  dmin;         /* min boundary distance robot-human over the step */

@@ -13,6 +13,8 @@
               and for windowed scenes with 'moving' / 'stay' padding           (misc.py:47-187, reader.py:44-166)
   g11_queryenv SARL with query_env = true driving the reference CrowdSim: per-step action values through
               env.onestep_lookahead                                            (multi_human_rl.py:35-55, crowd_sim.py:325-329)
+  g12_update_memory Explorer.update_memory in RL and imitation-learning mode on synthetic episodes: stored states
+              and value targets                                                (explorer.py:153-186)
   g10_trainer Trainer.optimize_batch / optimize_epoch (SGD momentum 0.9, MSE) on a seeded ValueNetwork and memory:
               weights before / after, losses                                   (trainer.py:19-82)
   g8_datagen  DataGen.gen_data_from_explore_in_mix on a synthetic recorded set: replay-then-freeze and
@@ -401,6 +403,47 @@ def g11_queryenv():
     print("g11_queryenv: %d arrays" % len(rec))
 
 
+def g12_update_memory():
+    """Reference Explorer.update_memory (explorer.py:153-186) on three synthetic episodes of 7 / 12 / 1 steps: RL mode
+    (value = r + gamma_bar * target_model(next state), terminal value = r) with a seeded SARL ValueNetwork as target
+    model, and imitation-learning mode (discounted tail sums; states transformed by the target policy)."""
+    from crowd_sim.envs.utils.state import FullState, ObservableState, JointState
+    from crowd_nav.utils.explorer import Explorer
+    from crowd_nav.utils.memory import ReplayMemory
+    rng = np.random.RandomState(12)
+    pol = _sarl_policy(41)
+    rec = dict(_state_dict_arrays(pol.model, "w__"))
+
+    class _Robot(object):
+        time_step, v_pref = 0.25, 1.0
+    lens = (7, 12, 1)
+    for mode in ("rl", "il"):
+        for e, L in enumerate(lens):
+            rewards = [float(x) for x in rng.uniform(-0.05, 0.0, L)]
+            rewards[-1] = 1.0 if e != 1 else -0.25
+            mem = ReplayMemory(100)
+            ex = Explorer(None, _Robot(), torch.device("cpu"), mem, 0.9, target_policy=pol)
+            ex.update_target_model(pol.model)
+            if mode == "rl":
+                states = [torch.from_numpy(rng.normal(0, 1, (5, 13)).astype(np.float32)) for _ in range(L)]
+                with torch.no_grad():
+                    ex.update_memory(states, None, rewards, imitation_learning=False)
+                rec["rl_e%d_states" % e] = np.stack([s_.numpy() for s_ in states])
+            else:
+                joint = []
+                for _ in range(L):
+                    me = FullState(*[float(x) for x in rng.uniform(-3, 3, 4)], 0.3, 0.0, 4.0, 1.0, 0.0)
+                    hs = [ObservableState(*[float(x) for x in rng.uniform(-3, 3, 4)], 0.3) for _ in range(5)]
+                    joint.append(JointState(me, hs))
+                ex.update_memory(joint, None, rewards, imitation_learning=True)
+                rec["il_e%d_states" % e] = np.stack([m[0].numpy() for m in mem.memory])
+            rec["%s_e%d_rewards" % (mode, e)] = np.array(rewards)
+            rec["%s_e%d_values" % (mode, e)] = np.array([float(m[1]) for m in mem.memory], np.float32)
+            rec["%s_e%d_mem_states" % (mode, e)] = np.stack([m[0].numpy() for m in mem.memory])
+    np.savez_compressed(os.path.join(OUT, "g12_update_memory.npz"), **rec)
+    print("g12_update_memory: %d arrays" % len(rec))
+
+
 def g10_trainer():
     """Reference Trainer (crowd_nav/utils/trainer.py:19-82) on a seeded SARL ValueNetwork and a seeded memory of
     (state [5,13], value [1]) pairs.  optimize_batch: the memory holds exactly one batch, so every step sees all rows
@@ -450,4 +493,4 @@ def g10_trainer():
     print("g10_trainer: %d arrays" % len(rec))
 
 
-FAMILIES = {"g10": g10_trainer, "g11": g11_queryenv, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}
+FAMILIES = {"g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}

@@ -95,6 +95,37 @@ def test_trainer_steps_match_reference_trainer(mode, golden_dir):
         np.testing.assert_allclose(v.numpy(), want, rtol=0, atol=1e-6, err_msg=k)
 
 
+@pytest.mark.parametrize("mode", ["rl", "il"])
+def test_value_targets_match_reference_update_memory(mode, golden_dir):
+    """rollout.value_targets (the batched Explorer.update_memory / DataGen.update_memory) against the REAL reference's
+    Explorer.update_memory (explorer.py:153-186; fixture tests/golden/g12_update_memory.npz): three episodes of 7 / 12 /
+    1 steps laid side by side as three envs, RL targets through a seeded target network, IL discounted tail sums."""
+    from modelcrowdnav_amd import _hip
+    from modelcrowdnav_amd.rollout import value_targets
+    g = np.load(os.path.join(golden_dir, "g12_update_memory.npz"))
+    torch.set_num_threads(1)
+    model = _model(seed=5)
+    _load_sd(model, g, "w__")
+    lens = [len(g["%s_e%d_rewards" % (mode, e)]) for e in range(3)]
+    T, E = max(lens) + 2, 3                       # two junk steps after the longest episode: must not be kept
+    rng = np.random.RandomState(1)
+    states = torch.from_numpy(rng.normal(0, 1, (T, E, 5, 13)).astype(np.float32))
+    rewards = torch.from_numpy(rng.uniform(-1, 1, (T, E)))
+    dones = torch.zeros(T, E, dtype=torch.bool)
+    infos = torch.zeros(T, E, dtype=torch.uint8)
+    for e, L in enumerate(lens):
+        states[:L, e] = torch.from_numpy(g["%s_e%d_mem_states" % (mode, e)])
+        rewards[:L, e] = torch.from_numpy(g["%s_e%d_rewards" % (mode, e)])
+        dones[L - 1, e] = True
+        infos[L - 1, e] = _hip.INFO_REACHGOAL if e != 1 else _hip.INFO_COLLISION
+    gbar = pow(0.9, 0.25 * 1.0)
+    s, v = value_targets(states, rewards, dones, infos, mode == "il", gbar, target_model=model, device=torch.device("cpu"))
+    want_v = np.concatenate([g["%s_e%d_values" % (mode, e)] for e in range(3)])
+    want_s = np.concatenate([g["%s_e%d_mem_states" % (mode, e)] for e in range(3)])
+    assert tuple(s.shape) == want_s.shape and np.array_equal(s.numpy(), want_s)         # (env, time) order = episode order
+    np.testing.assert_allclose(v.numpy(), want_v, rtol=0, atol=1e-6)
+
+
 def _dp_unequal_worker(rank, ws, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(ws), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

@@ -297,8 +297,9 @@ def extra_configs(device):
         env.sim_world = world
 
         def step4():
+            env.prefetch_world()             # SGAN on a side stream: overlaps the value-network look-ahead
             a, _ = pol4.predict_batch(env)
-            env.step(a)                      # asks sim_world (SGAN) for the humans' velocities
+            env.step(a)                      # picks the prefetched velocities up
         ms4 = _timed(step4, 20)
         ms_sgan = _timed(lambda: world(env.hpos), 20)
         out.append({"config": "4096 envs x 10 humans, model-based rollout: SGAN (pool-net, zara1_8) world model + SARL robot",

@@ -27,6 +27,8 @@ class VecModelCrowdSim(VecCrowdSim):
         self.track_human_times = False
         self.init_velocity = True
         self.human_policy_name = "given"
+        self._side = None            # side stream + event of prefetch_world()
+        self._prefetched = None
 
     def _case_sizes(self, config):
         return {"train": _UINT32_MAX - 2000, "val": config.getint("env", "val_size"),
@@ -35,11 +37,33 @@ class VecModelCrowdSim(VecCrowdSim):
     def step(self, actions, update=True, new_v=None, noise=None):
         """model_crowd_sim.py:347-441.  new_v: [E,N,2] velocities, or None to ask `sim_world`
         (a VecSGANWorld-style callable: positions [E,N,2] (+ noise) -> velocities [E,N,2])."""
+        if new_v is None and self._prefetched is not None:
+            new_v, ev = self._prefetched
+            self._prefetched = None
+            torch.cuda.current_stream(self.device).wait_event(ev)
         if new_v is None:
             if self.sim_world is None:
                 raise AttributeError("sim_world has to be set when new_v is not given")
             new_v = self.sim_world(self.hpos, noise) if noise is not None else self.sim_world(self.hpos)
         return super().step(actions, update=update, given_v=new_v)
+
+    def prefetch_world(self, noise=None):
+        """Start the world model's prediction for the COMING step on a side stream, so that it overlaps the robot's
+        policy (the value-network look-ahead reads the same state and does not need the prediction); the next
+        `step()` without `new_v` picks the result up.  The humans' reaction does not depend on the robot's action
+        (model_crowd_sim.py:398-407 feeds the world model the current human states only), so the order
+        prefetch -> predict -> step gives exactly the values of predict -> step."""
+        if self.sim_world is None:
+            raise AttributeError("sim_world has to be set")
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        cur = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(cur)          # after everything queued so far (the previous step, its readers)
+        with torch.cuda.stream(self._side):
+            v = self.sim_world(self.hpos, noise) if noise is not None else self.sim_world(self.hpos)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._prefetched = (v, ev)
 
     def onestep_lookahead(self, actions):
         return self.step(actions, update=False)

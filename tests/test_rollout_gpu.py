@@ -321,6 +321,23 @@ def test_model_crowd_sim_with_sgan_world(golden_dir):
         assert torch.equal(env.hpos, before + vel * env.time_step)
         assert torch.equal(env.hh_count, torch.zeros_like(env.hh_count))         # ModelCrowdSim does not count
     assert float(env.gtime[0]) == 12 * 0.25
+    # prefetch_world(): the world model on a side stream, overlapping the look-ahead -- the same trajectory, bit for bit
+    def run(prefetch):
+        e2 = H.make_vec_env(E, N, cls=VecModelCrowdSim)
+        e2.reset("test", test_cases=list(range(E)))
+        w2 = VecSGANWorld(gen, E, N, dev, time_step=e2.time_step, seed=0)
+        w2.fixed_noise = torch.randn(E, 8, generator=torch.Generator().manual_seed(3)).to(dev)
+        w2.init_constant_velocity(e2.hpos, e2.hvel)
+        e2.sim_world = w2
+        for t in range(10):
+            if prefetch:
+                e2.prefetch_world()
+            a, _ = pol.predict_batch(e2)
+            e2.step(a)
+        torch.cuda.synchronize()
+        return e2.hpos.clone(), e2.rpos.clone(), e2.step_rec.clone()
+    for x, y in zip(run(False), run(True)):
+        assert torch.equal(x, y)
 
 
 def _reference_targets(states, rewards, dones, infos, gamma_bar, il, target_model=None, rounds=None):

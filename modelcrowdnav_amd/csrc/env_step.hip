@@ -55,7 +55,7 @@ void env_step_kernel(const StepParams p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // carve (all offsets multiples of 16 B)
     float4  *sL      = reinterpret_cast<float4 *>(smem);                       // [nl_cap][BLOCK]
-    float4  *sAgF    = sL + (size_t)(NT ? 0 : p.nl_cap) * BLOCK;   // static-N kernels keep lines in VGPRs                          // [BLOCK]
+    float4  *sAgF    = sL + (size_t)(NT ? (MODE == MCN_HUMANS_ORCA ? NT / 2 : 0) : p.nl_cap) * BLOCK;   // static-N ORCA: the pairs' (u, dir) rows
     double2 *sPosD   = reinterpret_cast<double2 *>(sAgF + BLOCK);              // [BLOCK]
     double2 *sRobPos = sPosD + BLOCK;                                          // [BLOCK] per env slot
     double2 *sRobAct = sRobPos + BLOCK;                                        // [BLOCK]
@@ -152,18 +152,56 @@ void env_step_kernel(const StepParams p)
             float ox, oy;
             if constexpr (NT > 0) {
                 constexpr int NC = NT - 1 + VIS;
-                float4 cpv[NC > 0 ? NC : 1];
-                float crad[NC > 0 ? NC : 1];
+                // Each pair of humans builds its half-plane ONCE: the two humans' lines are (v + u/2, dir) and
+                // (v' - u/2, -dir) for the same (u, dir) (orca_static.hpp: orca_u_dir).  Lane h computes the pairs
+                // (h, h + s), s = 1 .. (NT-1)/2 around the env's ring of humans (for even NT the opposite pair goes to
+                // the lower index), parks (u, dir) in the LDS rows the run-time-N kernel uses for its lines, and every
+                // lane then reads its NT-1 half-planes back with the owner's sign.  Halves the dominant VALU block.
+                constexpr int FW = NT / 2;                        // forward pairs a lane may own
+                const float inv_th = 1.0f / c.orca_time_horizon;
+                const float inv_ts = 1.0f / (float)dt;
+                if constexpr (NT >= 2) {
+#pragma unroll
+                    for (int s_ = 1; s_ <= FW; ++s_) {
+                        int j = h + s_;
+                        j = j >= NT ? j - NT : j;
+                        // odd NT: distances 1 .. (NT-1)/2 cover every pair once; even NT: distance NT/2 is reached from
+                        // both ends, the lower index owns it
+                        const bool own = (2 * s_ < NT) || (h < j);
+                        float4 ud = make_float4(0, 0, 0, 0);
+                        if (own) ud = orca_u_dir(fpx, fpy, fvx, fvy, frad, sAgF[gbase + j], sRadF[gbase + j], inv_th, inv_ts);
+                        sL[(s_ - 1) * BLOCK + tid] = ud;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // env groups never straddle a wavefront
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                float4 Lnat[NC > 0 ? NC : 1];
+                float dd[NC > 0 ? NC : 1];
 #pragma unroll
                 for (int cidx = 0; cidx < NT - 1; ++cidx) {
                     const int j = cidx + (cidx >= h);
-                    cpv[cidx] = sAgF[gbase + j];
-                    crad[cidx] = sRadF[gbase + j];
+                    int sf = j - h;                               // ring distance from me to j
+                    sf = sf < 0 ? sf + NT : sf;
+                    const bool mine = (2 * sf < NT) || (2 * sf == NT && h < j);
+                    const int sb = NT - sf;                       // ring distance from j to me
+                    const int owner = mine ? tid : gbase + j;
+                    const int slot = (mine ? sf : sb) - 1;
+                    const float4 ud = sL[slot * BLOCK + owner];
+                    const float sg = mine ? 0.5f : -0.5f;
+                    Lnat[cidx] = make_float4(fvx + sg * ud.x, fvy + sg * ud.y, mine ? ud.z : -ud.z, mine ? ud.w : -ud.w);
+                    const float4 q = sAgF[gbase + j];
+                    const float ddx = fpx - q.x, ddy = fpy - q.y;
+                    dd[cidx] = dot2(ddx, ddy, ddx, ddy);
                 }
-                if constexpr (VIS) { cpv[NC - 1] = sRobF[slot]; crad[NC - 1] = sRobRadF[slot]; }
-                orca_solve_static<NC>(cpv, crad, fpx, fpy, fvx, fvy, frad, (float)attr.y,
-                                      (float)(goal.x - pos.x), (float)(goal.y - pos.y),
-                                      c.orca_neighbor_dist, c.orca_max_neighbors, c.orca_time_horizon, (float)dt, ox, oy);
+                if constexpr (VIS) {
+                    const float4 rq = sRobF[slot];
+                    Lnat[NC - 1] = orca_line_select(fpx, fpy, fvx, fvy, frad, rq, sRobRadF[slot], inv_th, inv_ts);
+                    const float ddx = fpx - rq.x, ddy = fpy - rq.y;
+                    dd[NC - 1] = dot2(ddx, ddy, ddx, ddy);
+                }
+                orca_solve_static_lines<NC>(Lnat, dd, (float)attr.y, (float)(goal.x - pos.x), (float)(goal.y - pos.y),
+                                            c.orca_neighbor_dist, c.orca_max_neighbors, ox, oy);
             } else {
                 GroupCand cand{sAgF, sRadF, make_float4(0, 0, 0, 0), 0.f, gbase, h, N - 1};
                 int ncand = N - 1;
@@ -345,7 +383,7 @@ static size_t step_smem_bytes(int block, int nl_cap)
 template <int BLOCK, int NT, int VIS, int MODE, int HH_T>
 static void launch_one(const StepParams &p, int blocks, hipStream_t stream)
 {
-    const size_t sm = step_smem_bytes(BLOCK, (NT || MODE != MCN_HUMANS_ORCA) ? 0 : p.nl_cap);
+    const size_t sm = step_smem_bytes(BLOCK, MODE != MCN_HUMANS_ORCA ? 0 : (NT ? NT / 2 : p.nl_cap));
     hipLaunchKernelGGL((env_step_kernel<BLOCK, NT, VIS, MODE, HH_T>), dim3(blocks), dim3(BLOCK), sm, stream, p);
 }
 

@@ -63,8 +63,11 @@ __device__ __forceinline__ float4 orca_line_merged(float px, float py, float vx,
 
 // orca_line_merged as one straight-line block: the cut-off-circle and the leg projections are both
 // evaluated and the result selected.  Same operations on the selected side, so the same bits.
-__device__ __forceinline__ float4 orca_line_select(float px, float py, float vx, float vy, float radius, float4 o,
-                                                   float orad, float inv_th, float inv_ts)
+// Returns (u.x, u.y, dir.x, dir.y): the half-plane is point = v + u / 2, direction = dir.
+// Every operation is odd-symmetric under swapping the two agents (relative position and velocity change sign, the
+// radius sum does not), so the pair's other half-plane is exactly (-u, -dir): env_step.hip builds each pair once.
+__device__ __forceinline__ float4 orca_u_dir(float px, float py, float vx, float vy, float radius, float4 o,
+                                             float orad, float inv_th, float inv_ts)
 {
     const float rpx = o.x - px, rpy = o.y - py;
     const float rvx = vx - o.z, rvy = vy - o.w;
@@ -94,7 +97,14 @@ __device__ __forceinline__ float4 orca_line_select(float px, float py, float vx,
     const float lux = dp2 * gx - rvx, luy = dp2 * gy - rvy;
     const float dx = circle ? uwy : gx, dy = circle ? -uwx : gy;
     const float ux = circle ? cux : lux, uy = circle ? cuy : luy;
-    return make_float4(vx + 0.5f * ux, vy + 0.5f * uy, dx, dy);
+    return make_float4(ux, uy, dx, dy);
+}
+
+__device__ __forceinline__ float4 orca_line_select(float px, float py, float vx, float vy, float radius, float4 o,
+                                                   float orad, float inv_th, float inv_ts)
+{
+    const float4 ud = orca_u_dir(px, py, vx, vy, radius, o, orad, inv_th, inv_ts);
+    return make_float4(vx + 0.5f * ud.x, vy + 0.5f * ud.y, ud.z, ud.w);
 }
 
 // 1-D LP on line NO (compile-time) against lines [0, NO).  DIR = false: closest point to (optx,opty);
@@ -281,6 +291,55 @@ __device__ __forceinline__ void orca_solve_static(float4 (&cpv)[NC > 0 ? NC : 1]
         for (int k = 0; k < NL; ++k) buf[k] = L[k];
         PrivLines PL{buf};
         lp3(PL, nl, fail, max_speed, rx, ry);
+    }
+    outx = rx; outy = ry;
+}
+
+// The same solve from half-planes built elsewhere: Lnat[c] is candidate c's half-plane (insertion order), dd[c] its
+// squared distance.  Sorting the finished lines by distance instead of the candidates before building them gives the
+// same lines in the same order (stable network, same keys).
+template <int NC>
+__device__ __forceinline__ void orca_solve_static_lines(float4 (&Lnat)[NC > 0 ? NC : 1], float (&dd)[NC > 0 ? NC : 1],
+                                                        float max_speed, float prefx, float prefy, float neighbor_dist,
+                                                        int max_neighbors, float &outx, float &outy)
+{
+    constexpr int NL = NC < kMaxLines ? (NC > 0 ? NC : 1) : kMaxLines;
+    static_assert(NC <= kMaxLines, "more candidates than line slots: the tail of the sorted list would be lost");
+    const float range_sq = neighbor_dist * neighbor_dist;
+    float d[NC > 0 ? NC : 1];
+    int nin = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const bool in = dd[c] < range_sq;
+        d[c] = in ? dd[c] : INFINITY;
+        nin += in;
+    }
+#pragma unroll
+    for (int i = 1; i < NC; ++i) {
+#pragma unroll
+        for (int j = i; j >= 1; --j) {
+            const bool sw = d[j] < d[j - 1];
+            const float td = sw ? d[j - 1] : d[j];       d[j - 1] = sw ? d[j] : d[j - 1];       d[j] = td;
+            const float4 a = Lnat[j - 1], b = Lnat[j];
+            Lnat[j - 1] = make_float4(sw ? b.x : a.x, sw ? b.y : a.y, sw ? b.z : a.z, sw ? b.w : a.w);
+            Lnat[j]     = make_float4(sw ? a.x : b.x, sw ? a.y : b.y, sw ? a.z : b.z, sw ? a.w : b.w);
+        }
+    }
+    int nl = nin < max_neighbors ? nin : max_neighbors;
+    if (nl > NL) nl = NL;
+    float4 (&L)[NL] = reinterpret_cast<float4 (&)[NL]>(Lnat);
+    float rx, ry;
+    if (dot2(prefx, prefy, prefx, prefy) > max_speed * max_speed) {
+        const float inv = 1.0f / sqrtf(dot2(prefx, prefy, prefx, prefy));
+        rx = max_speed * (prefx * inv); ry = max_speed * (prefy * inv);
+    } else {
+        rx = prefx; ry = prefy;
+    }
+    int fail = nl;
+    Lp2Step<0, NL>::run(L, nl, max_speed, prefx, prefy, rx, ry, fail);
+    if (fail < nl) {
+        float dist = 0.0f;
+        Lp3Step<0, NL>::run(L, nl, fail, max_speed, rx, ry, dist);
     }
     outx = rx; outy = ry;
 }

@@ -29,6 +29,10 @@
 
 namespace mcn {
 
+// crowds up to this size pre-filter the human-human overlaps inside the ORCA candidate loop (squared distances, no
+// sqrt); larger ones keep the separate loop: the extra live values push their unrolled solver past 168 VGPRs
+constexpr int kHhPreMaxN = 6;
+
 struct GroupCand {
     const float4 *sAg; const float *sRad;   // block-level staged humans
     float4 rob; float rob_rad;              // robot as seen by humans (if visible)
@@ -147,6 +151,8 @@ void env_step_kernel(const StepParams p)
 
     // ---- K1: human action ----
     double hax = 0, hay = 0;
+    int hh_pre = 0;                 // static-N ORCA kernels pre-filter the human-human overlaps while they hold the
+    bool border_pre = false;        // squared distances
     if (active) {
         if constexpr (MODE == MCN_HUMANS_ORCA) {
             float ox, oy;
@@ -193,6 +199,16 @@ void env_step_kernel(const StepParams p)
                     const float4 q = sAgF[gbase + j];
                     const float ddx = fpx - q.x, ddy = fpy - q.y;
                     dd[cidx] = dot2(ddx, ddy, ddx, ddy);
+                    if constexpr (HH_T != 0 && NT <= kHhPreMaxN) {
+                        // human-human overlap pre-filter on the squared distance ORCA needs anyway (no sqrt): surely
+                        // overlapping below (R - 1e-3)^2, surely apart above (R + 1e-3)^2, the exact float64 test decides
+                        // in between (K2)
+                        const float R = (float)attr.x + (sRadF[gbase + j] - 0.01f - (float)c.orca_safety_space);
+                        const float lo = R - 1e-3f, hi = R + 1e-3f;
+                        const bool sure = (j > h) & (lo > 0.0f) & (dd[cidx] < lo * lo);
+                        hh_pre += sure ? 1 : 0;
+                        border_pre = border_pre | ((j > h) & !sure & (dd[cidx] < hi * hi));
+                    }
                 }
                 if constexpr (VIS) {
                     const float4 rq = sRobF[slot];
@@ -240,7 +256,9 @@ void env_step_kernel(const StepParams p)
         // staged tile decides every pair that is not within 1e-3 of touching; only if some lane of the
         // wavefront holds a borderline pair does the wave take the exact float64 path.
         bool borderline = false;
-        if (active) {
+        if constexpr (MODE == MCN_HUMANS_ORCA && NT > 0 && NT <= kHhPreMaxN) {
+            hh = hh_pre; borderline = border_pre;
+        } else if (active) {
             for (int j = h + 1; j < N; ++j) {
                 const float4 q = sAgF[gbase + j];
                 const float dxf = fpx - q.x, dyf = fpy - q.y;

@@ -301,18 +301,31 @@ def extra_configs(device):
             a, _ = pol4.predict_batch(env)
             env.step(a)                      # picks the prefetched velocities up
         ms4 = _timed(step4, 20)
-        ms_sgan = _timed(lambda: world(env.hpos), 20)
+        ms_sgan = _timed(lambda: world(env.hpos), 96)           # three host noise blocks (VecSGANWorld.draw_noise)
         out.append({"config": "4096 envs x 10 humans, model-based rollout: SGAN (pool-net, zara1_8) world model + SARL robot",
                     "ms_per_step": round(ms4, 4), "env_steps_per_sec": round(E / ms4 * 1e3, 1),
                     "sgan_step_ms": round(ms_sgan, 4),
-                    # ~0.69 MFLOP per pedestrian for the pooling generator at N = 10 (8 encoder LSTM steps,
-                    # N pool-net MLPs 48 -> 512 -> 8 per pedestrian, context MLP, decoder LSTM step)
-                    "roofline": {"bound": "mfma", "kernel": "mcn::sgan_encode_kernel + mcn::sgan_decode_kernel",
-                                 "achieved": round(0.69e6 * E * N / ms_sgan / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                                 "unit": "TFLOP/s", "frac": round(0.69e6 * E * N / ms_sgan / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
-                                 "traffic": None, "algorithmic_flop_per_launch": int(0.69e6 * E * N),
-                                 "avg_launch_us": round(ms_sgan * 1e3, 1), "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}})
+                    # ~0.69 MFLOP per pedestrian for the pooling generator at N = 10 as the reference
+                    # writes it (8 encoder LSTM steps, N pool-net MLPs 48 -> 512 -> 8 per pedestrian, context MLP,
+                    # decoder LSTM step): `achieved` / `frac` follow that definition.  The kernels execute fewer: the
+                    # pool-net's first layer is split into a per-partner and a per-pair part and the spatial embeddings
+                    # are folded into the layers they feed (sgan_step.hip); `executed_*` counts the MFMAs really issued
+                    # (per 16 pedestrians: encoder 576, pool 2 x 1 064, decoder 160; 2 048 FLOP each).
+                    "roofline": _sgan_roofline(E, N, ms_sgan)})
     return out
+
+
+def _sgan_roofline(E, N, ms):
+    algorithmic = 0.69e6 * E * N
+    tiles = (E * N + 15) // 16
+    executed = tiles * (576 + ((N + 4) // 5) * 1064 + 160) * 2048
+    return {"bound": "mfma", "kernel": "mcn::sgan_encode_kernel + mcn::sgan_pool_kernel + mcn::sgan_decode_kernel",
+            "achieved": round(algorithmic / ms / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(algorithmic / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+            "algorithmic_flop_per_launch": int(algorithmic), "executed_flop_per_launch": int(executed),
+            "executed_achieved": round(executed / ms / 1e9, 2),
+            "executed_frac": round(executed / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
+            "avg_launch_us": round(ms * 1e3, 1), "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}
 
 
 def cpu_baseline(N, seconds):

@@ -266,17 +266,18 @@ int mcn_sarl_lookahead_env(const mcn_sarl_net *net, const mcn_env_state *st, con
  * ---------------------------------------------------------------------------------------------- */
 
 /* Device pointers to packed fragments of one TrajectoryGenerator (shipped architecture: embedding 16,
- * encoder/decoder hidden 32, mlp 64, bottleneck 8, noise 8 'global', pool hidden 512, no batch norm). */
+ * encoder/decoder hidden 32, mlp 64, bottleneck 8, noise 8 'global', pool hidden 512, no batch norm).
+ * The three spatial_embedding layers (Linear(2, 16), models.py:47,120,186) feed a Linear / LSTM input directly, so the
+ * packer folds them into it (in float64, rounded once): a layer "W [emb | h] , b" arrives here as
+ * "[W_emb W_se | W_h] , b + W_emb b_se" with 2 + 32 input columns.  Input tile 0 carries the displacement: x in slot
+ * 0, y in slot 4 (both in MFMA k-step 0), tiles 1-2 the 32 hidden features. */
 typedef struct mcn_sgan_net {
-    const float *w_eemb, *b_eemb;     /* encoder.spatial_embedding */
-    const float *w_elstm, *b_elstm;   /* encoder.encoder [weight_ih_l0 | weight_hh_l0], bias_ih_l0 + bias_hh_l0 */
-    const float *w_pemb, *b_pemb;     /* pool_net.spatial_embedding      (pooling models only) */
-    const float *w_p1, *b_p1;         /* pool_net.mlp_pre_pool.0 */
-    const float *w_p2, *b_p2;         /* pool_net.mlp_pre_pool.2 */
+    const float *w_elstm, *b_elstm;   /* encoder: [weight_ih_l0 W_se | weight_hh_l0], bias_ih + bias_hh + weight_ih b_se */
+    const float *w_p1, *b_p1;         /* pool_net.mlp_pre_pool.0 folded with pool_net.spatial_embedding (pooling only) */
+    const float *w_p2, *b_p2;         /* pool_net.mlp_pre_pool.2                                         (pooling only) */
     const float *w_c1, *b_c1;         /* mlp_decoder_context.0 */
     const float *w_c2, *b_c2;         /* mlp_decoder_context.2 */
-    const float *w_demb, *b_demb;     /* decoder.spatial_embedding */
-    const float *w_dlstm, *b_dlstm;   /* decoder.decoder [weight_ih_l0 | weight_hh_l0], bias sum */
+    const float *w_dlstm, *b_dlstm;   /* decoder: folded like the encoder's */
     const float *w_h2p, *b_h2p;       /* decoder.hidden2pos */
     int32_t pooling;                  /* 1: pooling_type == 'pool_net', 0: none */
 } mcn_sgan_net;

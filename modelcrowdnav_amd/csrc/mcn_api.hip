@@ -19,6 +19,9 @@ int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double
                   double gamma_pow, int kinematics, void *workspace, double *values, int32_t *best, double *best_val,
                   float *attention, const double *next_hpos, const double *next_hvel, const double *reward_in,
                   int E, int N, hipStream_t stream);
+#ifdef MCN_DIAG
+int read_pool_clock(void *dst, size_t bytes);
+#endif
 int launch_sgan(const mcn_sgan_net *net, double *hist, int push_slot, int oldest, const double *cur_pos,
                 const float *noise, const int32_t *hcount, void *workspace, double *out_vel, float *out_rel,
                 double time_step, int E, int N, hipStream_t stream);
@@ -279,7 +282,7 @@ int mcn_sarl_lookahead_env(const mcn_sarl_net *net, const mcn_env_state *st, con
 int64_t mcn_sgan_workspace_bytes(int32_t E, int32_t N)
 {
     if (E <= 0 || N <= 0) return 0;
-    return (int64_t)E * N * (32 + 4) * 4;
+    return (int64_t)E * N * (32 + 4 + 8) * 4;     // encoder state, last position / displacement, pooled features
 }
 
 int mcn_sgan_step(const mcn_sgan_net *net, double *hist, int32_t push_slot, int32_t oldest, const double *cur_pos,
@@ -290,8 +293,8 @@ int mcn_sgan_step(const mcn_sgan_net *net, double *hist, int32_t push_slot, int3
     if (E <= 0 || N <= 0 || N > MCN_MAX_HUMANS) return MCN_EINVAL;
     if (push_slot < 0 || push_slot > 7 || oldest < 0 || oldest > 7 || !(time_step > 0)) return MCN_EINVAL;
     const float *const *fp = reinterpret_cast<const float *const *>(net);
-    for (int k = 0; k < 20; ++k) {
-        const bool pool_only = (k >= 4 && k < 10);
+    for (int k = 0; k < 14; ++k) {
+        const bool pool_only = (k >= 2 && k < 6);
         if (!fp[k] && !(pool_only && !net->pooling)) return MCN_EINVAL;
     }
     return mcn::launch_sgan(net, hist, push_slot, oldest, cur_pos, noise, hcount, workspace, out_vel, out_rel,
@@ -299,6 +302,8 @@ int mcn_sgan_step(const mcn_sgan_net *net, double *hist, int32_t push_slot, int3
 }
 
 #ifdef MCN_DIAG
+// diagnostic build only: [workgroup][4] = s_memtime, s_memrealtime before / after the SGAN pool kernel's unit loop
+int mcn_debug_pool_clock(void *dst_host, int64_t bytes) { return mcn::read_pool_clock(dst_host, (size_t)bytes); }
 // diagnostic build only: copies the rollout kernel's time stamps to host memory, returns the number of 8-byte words
 int mcn_debug_stamps(void *dst_host, int64_t bytes) { return mcn::read_stamps(dst_host, (size_t)bytes); }
 // per-wavefront counts of the data-dependent paths taken: [wave][4] = 3-D LP, restarts, overlap sqrt, goal sqrt

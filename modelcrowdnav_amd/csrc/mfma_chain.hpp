@@ -13,9 +13,19 @@ namespace mcn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ReLU as ONE vector instruction: fmaxf(x, 0) compiles to two under IEEE rules (v_max x, x to quiet a signalling NaN,
+// then v_max 0, x), and so does every float form the optimiser recognises as a maximum.  As signed integers the
+// negative floats (and -0) are < 0 and the others keep their order, so max(bits, 0) is the same function.
+__device__ __forceinline__ float relu_f32(float x)
+{
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
 // out[n] = act( bias[n] (+ init) + sum_t in[t] x W[n][t] ), two accumulators in flight per step so
 // back-to-back dependent MFMAs (40-cycle latency vs 32-cycle issue) never stall the pipe.
-template <int KT, int NT, bool RELU>
+// FIRST: k-steps of input tile 0 that carry anything (a 2-vector packed into slots 0 and 4 needs one).
+template <int KT, int NT, bool RELU, int FIRST = 4>
 __device__ __forceinline__ void dense(const f32x4 (&in)[KT], f32x4 (&out)[NT], const float4 *__restrict__ wf,
                                       const float4 *__restrict__ bf, int lane)
 {
@@ -31,22 +41,82 @@ __device__ __forceinline__ void dense(const f32x4 (&in)[KT], f32x4 (&out)[NT], c
             const float4 w0 = wf[(n * KT + t) * 64 + lane];
             float4 w1 = make_float4(0, 0, 0, 0);
             if (two) w1 = wf[((n + 1) * KT + t) * 64 + lane];
+            const int steps = t == 0 ? FIRST : 4;
             a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, in[t][0], a0, 0, 0, 0);
             if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, in[t][0], a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, in[t][1], a0, 0, 0, 0);
-            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, in[t][1], a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, in[t][2], a0, 0, 0, 0);
-            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, in[t][2], a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, in[t][3], a0, 0, 0, 0);
-            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, in[t][3], a1, 0, 0, 0);
+            if (steps > 1) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, in[t][1], a0, 0, 0, 0);
+                if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, in[t][1], a1, 0, 0, 0);
+            }
+            if (steps > 2) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, in[t][2], a0, 0, 0, 0);
+                if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, in[t][2], a1, 0, 0, 0);
+            }
+            if (steps > 3) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, in[t][3], a0, 0, 0, 0);
+                if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, in[t][3], a1, 0, 0, 0);
+            }
         }
         if (RELU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { a0[r] = fmaxf(a0[r], 0.0f); a1[r] = fmaxf(a1[r], 0.0f); }
+            for (int r = 0; r < 4; ++r) { a0[r] = relu_f32(a0[r]); a1[r] = relu_f32(a1[r]); }
         }
         out[n] = a0;
         if (two) out[n + 1] = a1;
     }
+}
+
+// Same layer with its fragments RESIDENT in LDS (small networks whose weights fit next to the workgroup for the whole
+// kernel): w = [NT][KT][64] float4 as packed by mcn_pack_linear, bq = biases by (output tile, lane group): the float4
+// of features 16n + 4q .. + 3 at bq[4n + q] (column 0 of the packed bias fragment).
+template <int KT, int NT, bool RELU, int FIRST = 4>
+__device__ __forceinline__ void dense_lds(const f32x4 (&in)[KT], f32x4 (&out)[NT], const float4 *w, const float4 *bq,
+                                          int lane)
+{
+    const int q = lane >> 4;
+#pragma unroll
+    for (int n = 0; n < NT; n += 2) {
+        const bool two = (n + 1 < NT);
+        f32x4 a0, a1 = {0, 0, 0, 0};
+        { const float4 b = bq[4 * n + q]; a0 = (f32x4){b.x, b.y, b.z, b.w}; }
+        if (two) { const float4 b = bq[4 * n + 4 + q]; a1 = (f32x4){b.x, b.y, b.z, b.w}; }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const float4 w0 = w[(n * KT + t) * 64 + lane];
+            float4 w1 = make_float4(0, 0, 0, 0);
+            if (two) w1 = w[((n + 1) * KT + t) * 64 + lane];
+            const int steps = t == 0 ? FIRST : 4;
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, in[t][0], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, in[t][0], a1, 0, 0, 0);
+            if (steps > 1) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, in[t][1], a0, 0, 0, 0);
+                if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, in[t][1], a1, 0, 0, 0);
+            }
+            if (steps > 2) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, in[t][2], a0, 0, 0, 0);
+                if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, in[t][2], a1, 0, 0, 0);
+            }
+            if (steps > 3) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, in[t][3], a0, 0, 0, 0);
+                if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, in[t][3], a1, 0, 0, 0);
+            }
+        }
+        if (RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a0[r] = relu_f32(a0[r]); a1[r] = relu_f32(a1[r]); }
+        }
+        out[n] = a0;
+        if (two) out[n + 1] = a1;
+    }
+}
+
+// copy a packed layer into LDS (call from every thread of the workgroup, barrier afterwards)
+template <int THREADS>
+__device__ __forceinline__ void lds_fill_layer(float4 *w_lds, float4 *bq_lds, const float4 *__restrict__ wf,
+                                               const float4 *__restrict__ bf, int KT, int NT, int tid)
+{
+    for (int i = tid; i < NT * KT * 64; i += THREADS) w_lds[i] = wf[i];
+    for (int i = tid; i < NT * 4; i += THREADS) bq_lds[i] = bf[(i >> 2) * 64 + (i & 3) * 16];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -147,7 +217,7 @@ __device__ __forceinline__ void dense_staged(const f32x4 (&in)[KT], const f32x4 
                 }
                 if (RELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { a0[r] = fmaxf(a0[r], 0.0f); a1[r] = fmaxf(a1[r], 0.0f); }
+                    for (int r = 0; r < 4; ++r) { a0[r] = relu_f32(a0[r]); a1[r] = relu_f32(a1[r]); }
                 }
                 out[n] = a0;
                 if (two) out[n + 1] = a1;

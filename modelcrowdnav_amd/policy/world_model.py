@@ -52,6 +52,7 @@ class VecSGANWorld(object):
         if seed is not None:
             self._gen.manual_seed(int(seed))
         self.fixed_noise = None      # [E,8] float32 device tensor: used instead of fresh draws (reproducible runs)
+        self._noise_buf, self._noise_at = None, 0
 
     def reset_history(self, hist):
         """hist: [E,8,N,2] positions, oldest frame first (datagen.py:423-430 writes the last obs_len frames)."""
@@ -63,8 +64,17 @@ class VecSGANWorld(object):
         k = torch.arange(7, -1, -1, dtype=torch.float64, device=self.device).view(1, 8, 1, 1)
         self.reset_history(pos.unsqueeze(1) - vel.unsqueeze(1) * (k * self.time_step))
 
+    _NOISE_BLOCK = 32
+
     def draw_noise(self):
-        return torch.randn(self.E, 8, generator=self._gen).to(self.device)
+        """One [E, 8] standard-normal sample per call (sgan/models.py:475-480 draws it on the host), taken from blocks
+        of `_NOISE_BLOCK` calls drawn and uploaded together: one host draw + copy per 32 world-model steps."""
+        if self._noise_buf is None or self._noise_at == self._NOISE_BLOCK:
+            host = torch.randn(self._NOISE_BLOCK, self.E, 8, generator=self._gen)
+            self._noise_buf = host.to(self.device)
+            self._noise_at = 0
+        self._noise_at += 1
+        return self._noise_buf[self._noise_at - 1]
 
     def __call__(self, cur_pos, noise=None, hcount=None):
         """cur_pos [E,N,2] float64 -> velocities [E,N,2] float64 (a view reused by the next call).

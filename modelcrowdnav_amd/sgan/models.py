@@ -50,9 +50,27 @@ class _PoolHiddenNet(nn.Module):
 
 
 class _SganNet(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("w_eemb", "b_eemb", "w_elstm", "b_elstm", "w_pemb", "b_pemb", "w_p1", "b_p1",
-                                          "w_p2", "b_p2", "w_c1", "b_c1", "w_c2", "b_c2", "w_demb", "b_demb",
-                                          "w_dlstm", "b_dlstm", "w_h2p", "b_h2p")] + [("pooling", C.c_int32)]
+    _fields_ = [(n, C.c_void_p) for n in ("w_elstm", "b_elstm", "w_p1", "b_p1", "w_p2", "b_p2", "w_c1", "b_c1",
+                                          "w_c2", "b_c2", "w_dlstm", "b_dlstm", "w_h2p", "b_h2p")] + [("pooling", C.c_int32)]
+
+
+def _fold_embedding(W, b, W_se, b_se):
+    """A layer W [nout, 16 + h] applied to [spatial_embedding(d), h] equals [W_e W_se | W_h] applied to [d, h] with
+    bias b + W_e b_se (the embedding is a plain Linear(2, 16): sgan/models.py:47,66 / 120,142 / 186,221-223).
+    Composed in float64 and rounded once."""
+    W, W_se = W.astype(np.float64), W_se.astype(np.float64)
+    Wf = np.concatenate([W[:, :16] @ W_se, W[:, 16:]], 1)
+    bf = b.astype(np.float64) + W[:, :16] @ b_se.astype(np.float64)
+    return Wf.astype(np.float32), bf.astype(np.float32)
+
+
+def _kmap_rel_h():
+    """Input tiles of a folded layer: tile 0 = displacement (x in slot 0, y in slot 4: one MFMA k-step), tiles 1-2 =
+    the 32 hidden features."""
+    m = np.full(48, -1, np.int32)
+    m[0], m[4] = 0, 1
+    m[16:48] = 2 + np.arange(32)
+    return m
 
 
 def _ident(kin, tiles, offset=0):
@@ -113,18 +131,19 @@ class TrajectoryGenerator(nn.Module):
             W = np.concatenate([sd[prefix + ".weight_ih_l0"], sd[prefix + ".weight_hh_l0"]], 1)     # [128, 16+32]
             return W, sd[prefix + ".bias_ih_l0"] + sd[prefix + ".bias_hh_l0"]
 
-        put("eemb", sd["encoder.spatial_embedding.weight"], sd["encoder.spatial_embedding.bias"], _ident(2, 1), 1)
-        put("elstm", *lstm("encoder.encoder"), _ident(48, 3), 3)
+        put("elstm", *_fold_embedding(*lstm("encoder.encoder"), sd["encoder.spatial_embedding.weight"],
+                                      sd["encoder.spatial_embedding.bias"]), _kmap_rel_h(), 3)
         if self.pooling_type:
-            put("pemb", sd["pool_net.spatial_embedding.weight"], sd["pool_net.spatial_embedding.bias"], _ident(2, 1), 1)
-            put("p1", sd["pool_net.mlp_pre_pool.0.weight"], sd["pool_net.mlp_pre_pool.0.bias"], _ident(48, 3), 3)
+            put("p1", *_fold_embedding(sd["pool_net.mlp_pre_pool.0.weight"], sd["pool_net.mlp_pre_pool.0.bias"],
+                                       sd["pool_net.spatial_embedding.weight"], sd["pool_net.spatial_embedding.bias"]),
+                _kmap_rel_h(), 3)
             put("p2", sd["pool_net.mlp_pre_pool.2.weight"], sd["pool_net.mlp_pre_pool.2.bias"], _ident(512, 32), 32)
             put("c1", sd["mlp_decoder_context.0.weight"], sd["mlp_decoder_context.0.bias"], _ident(40, 3), 3)
         else:
             put("c1", sd["mlp_decoder_context.0.weight"], sd["mlp_decoder_context.0.bias"], _ident(32, 2), 2)
         put("c2", sd["mlp_decoder_context.2.weight"], sd["mlp_decoder_context.2.bias"], _ident(64, 4), 4)
-        put("demb", sd["decoder.spatial_embedding.weight"], sd["decoder.spatial_embedding.bias"], _ident(2, 1), 1)
-        put("dlstm", *lstm("decoder.decoder"), _ident(48, 3), 3)
+        put("dlstm", *_fold_embedding(*lstm("decoder.decoder"), sd["decoder.spatial_embedding.weight"],
+                                      sd["decoder.spatial_embedding.bias"]), _kmap_rel_h(), 3)
         put("h2p", sd["decoder.hidden2pos.weight"], sd["decoder.hidden2pos.bias"], _ident(32, 2), 2)
         net.pooling = 1 if self.pooling_type else 0
         self._packed = (version, (net, keep))

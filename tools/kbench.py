@@ -15,6 +15,31 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
+def sgan_bench(E, N, iters):
+    """One SGANWorld call (ring push + encoder + pool-net + decoder) for E scenes of N pedestrians."""
+    from modelcrowdnav_amd.policy.world_model import VecSGANWorld, generator_from_arrays
+    dev = torch.device("cuda", 0)
+    gen = generator_from_arrays(np.load(os.path.join(ROOT, "tests", "golden", "g6_sgan.npz")), "p", dev)
+    world = VecSGANWorld(gen, E, N, dev, time_step=0.25, seed=0)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    pos = (torch.rand(E, N, 2, dtype=torch.float64, generator=g) * 8 - 4).to(dev)
+    vel = (torch.rand(E, N, 2, dtype=torch.float64, generator=g) - 0.5).to(dev)
+    world.init_constant_velocity(pos, vel)
+    for _ in range(3):
+        world(pos)
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(iters):
+        world(pos)
+    t1.record()
+    torch.cuda.synchronize()
+    ms = t0.elapsed_time(t1) / iters
+    tf = 0.69e6 * E * N / ms / 1e9
+    print("SGAN step N=%d E=%d: %.1f us/call  %.1f TFLOP/s algorithmic (%.1f %% of the fp32 MFMA peak %.1f)" % (
+        N, E, ms * 1e3, tf, 100 * tf / bench.MFMA_F32_PEAK_TFLOPS, bench.MFMA_F32_PEAK_TFLOPS), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--humans", type=str, default="5", help="humans per env (a comma list with --sarl)")
@@ -26,7 +51,13 @@ def main():
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--sarl", action="store_true")
     ap.add_argument("--rollout", type=int, default=0, help="time mcn_env_rollout with this many steps per launch")
+    ap.add_argument("--sgan", action="store_true", help="time mcn_sgan_step (shipped pool-net weights) at --sizes x --humans")
     a = ap.parse_args()
+    if a.sgan:
+        for N in [int(x) for x in str(a.humans).split(",")]:
+            for E in [int(x) for x in a.sizes.split(",")]:
+                sgan_bench(E, N, a.iters)
+        return
     if not a.sarl:
         a.humans = int(a.humans)
     if a.rollout:

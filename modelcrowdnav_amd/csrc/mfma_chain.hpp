@@ -126,12 +126,17 @@ __device__ __forceinline__ void lds_fill_layer(float4 *w_lds, float4 *bq_lds, co
 // conflict-free ds_read_b128 (consecutive lanes, consecutive 16-B slots).  While chunk c is being
 // multiplied, the loads of chunk c+1 are already in flight (issued before the MFMAs, written to the other
 // buffer after them); one barrier per chunk.  Every thread of the workgroup must call this uniformly.
-constexpr int kStageThreads = 256;
-// output tiles per staged chunk: 4 for layers with <= 7 input tiles, 2 for the 10-tile ones, so that a chunk is
-// at most 32 KiB and two workgroups (2 x 2 buffers + bias tails = 2 x 72 KiB) fit the CU's 160 KiB of LDS
-__host__ __device__ constexpr int chunk_tiles(int KT) { return KT > 16 ? 1 : (KT > 7 ? 2 : 4); }
-constexpr int kStageFloat4 = 32 * 64;                            // max over layers of chunk_tiles(KT) * KT * 64 (32 KiB)
-constexpr int kStageBias = 4 * 64;                               // bias fragments of the chunk's output tiles
+#ifndef MCN_STAGE_WAVES
+#define MCN_STAGE_WAVES 4
+#endif
+constexpr int kStageThreads = 64 * MCN_STAGE_WAVES;
+// output tiles per staged chunk: with 4 wavefronts per workgroup (two workgroups per CU: 2 x 2 buffers + bias tails =
+// 2 x 72 KiB of the CU's 160 KiB) 4 for layers with <= 7 input tiles and 2 for the 10-tile ones, i.e. chunks of at most
+// 32 KiB; with 8 wavefronts (one workgroup per CU) twice that.
+constexpr int kChunkScale = MCN_STAGE_WAVES >= 8 ? 2 : 1;
+__host__ __device__ constexpr int chunk_tiles(int KT) { return kChunkScale * (KT > 16 ? 1 : (KT > 7 ? 2 : 4)); }
+constexpr int kStageFloat4 = kChunkScale * 32 * 64;              // max over layers of chunk_tiles(KT) * KT * 64
+constexpr int kStageBias = kChunkScale * 4 * 64;                 // bias fragments of the chunk's output tiles
 
 struct WeightStage {
     float4 *buf;      // LDS, 2 * (kStageFloat4 + kStageBias) float4

@@ -79,7 +79,7 @@ __device__ __forceinline__ double norm2d(double x0, double x1) { return sqrt(fma
 
 constexpr int kSarlWaves = kStageThreads / 64;     // 8 wavefronts share one LDS weight stage (2 per SIMD)
 
-__global__ __launch_bounds__(kSarlWaves * 64, 2) void sarl_value_kernel(const SarlParams p)
+__global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl_value_kernel(const SarlParams p)
 {
     __shared__ float4 s_stage[2 * (kStageFloat4 + kStageBias)];
     const WeightStage S{s_stage, (int)threadIdx.x};

@@ -80,14 +80,14 @@ __global__ void k(float *out, unsigned long long *cyc, int iters)
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int i = 0; i < 12; ++i) {
-                    const int v = __builtin_bit_cast(int, acc[(i + 6) % 12][r]);
+                    const float f_ = acc[(i + 6) % 12][r]; const int v = __builtin_bit_cast(int, f_);
                     acc[i] = MFMA(a, __builtin_bit_cast(float, v > 0 ? v : 0), acc[i]);
                 }
         } else if (VARIANT == 9 || VARIANT == 10) {   // 20 v_max_i32 READ MFMA results (nothing reads theirs back)
             int keep[20];
             if (VARIANT == 9) {             // all together, ahead of the MFMAs
 #pragma unroll
-                for (int i = 0; i < 20; ++i) { const int v = __builtin_bit_cast(int, acc[i % 5][i / 5]); keep[i] = v > 0 ? v : 0; }
+                for (int i = 0; i < 20; ++i) { const float f_ = acc[i % 5][i / 5]; const int v = __builtin_bit_cast(int, f_); keep[i] = v > 0 ? v : 0; }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -101,13 +101,52 @@ __global__ void k(float *out, unsigned long long *cyc, int iters)
                         acc[i] = MFMA(a, b, acc[i]);
                         const int n = r * 12 + i;
                         if ((n & 1) && n / 2 < 20) {
-                            const int v = __builtin_bit_cast(int, acc[(i + 6) % 12][r]); keep[n / 2] = v > 0 ? v : 0;
+                            const float f_ = acc[(i + 6) % 12][r]; const int v = __builtin_bit_cast(int, f_); keep[n / 2] = v > 0 ? v : 0;
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
             }
 #pragma unroll
             for (int i = 0; i < 20; ++i) x[i] = __builtin_bit_cast(float, keep[i] ^ __builtin_bit_cast(int, x[i]));
+        } else if (VARIANT >= 11 && VARIANT <= 13) {  // SARL's ratio: 16 bytes of A operand per lane per 4 MFMAs
+            float acc_w = 0.f;
+            if (VARIANT == 11) {            // 12 ds_read_b128 per 48 MFMAs, consumed an iteration later
+                float4 w[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) w[i] = lds[((it * 12 + i) * 64 + lane) & 2047];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) acc[i] = MFMA(a, b, acc[i]);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) acc_w += w[i].x + w[i].w;
+            } else if (VARIANT == 12) {     // the same bytes as 24 ds_read_b64
+                float2 w[24];
+                const float2 *l2 = reinterpret_cast<const float2 *>(lds);
+#pragma unroll
+                for (int i = 0; i < 24; ++i) w[i] = l2[((it * 24 + i) * 64 + lane) & 4095];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) acc[i] = MFMA(a, b, acc[i]);
+#pragma unroll
+                for (int i = 0; i < 24; ++i) acc_w += w[i].x + w[i].y;
+            } else {                        // the same bytes as 12 global_load_dwordx4 from an L2-resident table
+                float4 w[12];
+                const float4 *g4 = reinterpret_cast<const float4 *>(out);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) w[i] = g4[((it * 12 + i) * 64 + lane) & 4095];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) acc[i] = MFMA(a, b, acc[i]);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) acc_w += w[i].x + w[i].w;
+            }
+            a += acc_w * 1e-30f;
         } else if (VARIANT == 5) {          // srcC from another register than vdst once per chain of 4
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
@@ -155,6 +194,9 @@ int main()
     run<6>("every MFMA writes another register block than its srcC");
     run<7>("5 chains restart from one shared srcC block each round");
     run<8>("B operand = v_max_i32 of another accumulator's element");
+    run<11>("12 ds_read_b128 per 48 MFMAs (one per 4: SARL's ratio)");
+    run<12>("24 ds_read_b64 per 48 MFMAs (same bytes)");
+    run<13>("12 global_load_dwordx4 per 48 MFMAs (same bytes, L2)");
     run<9>("20 v_max_i32 read MFMA results, all ahead of the 48 MFMAs");
     run<10>("20 v_max_i32 read MFMA results, one per second MFMA");
     return 0;

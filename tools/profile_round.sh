@@ -57,6 +57,17 @@ json.dump({"note": note + " One kbench --rollout T run per launch length T.", "k
 PY
 python3 tools/pmc_sq_summary.py "$OUT/sq_roll,$OUT/sq_step,$OUT/sq_given" "$DST/${TAG}_pmc_sq.json" \
     --spec "env_rollout_quad_kernel<5=rollout:4096:5:200;env_step_quad_kernel<5=quad:4096:5:1;env_step_kernel<256, 5, 0, 0=fused:1048576:5:1;env_pair_kernel<5=pairwise:1048576:5:1"
+# 1c. matrix-pipe counters of the network kernels (SARL look-ahead, SGAN step): one pass each
+MF="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
+cd /tmp
+rocprofv3 --pmc $MF --output-format csv -d "$OUT/mfma_sarl" -o pmc -- python3 "$KB" --sarl --humans 5 \
+    > "$OUT/mfma_sarl.log" 2>&1 || { tail -5 "$OUT/mfma_sarl.log"; exit 1; }
+rocprofv3 --pmc $MF --output-format csv -d "$OUT/mfma_sgan" -o pmc -- python3 "$KB" --sgan --humans 10 --sizes 4096 --iters 20 \
+    > "$OUT/mfma_sgan.log" 2>&1 || { tail -5 "$OUT/mfma_sgan.log"; exit 1; }
+cd "$ROOT"
+mkdir -p "$OUT/mfma_all" && cp -r "$OUT/mfma_sarl" "$OUT/mfma_sgan" "$OUT/mfma_all/"
+python3 tools/pmc_mfma.py "$OUT/mfma_all" "$DST/${TAG}_pmc_mfma.json"
+echo "pmc MFMA done"
 # 2. the bench command itself under kernel tracing (same flags as the driver's N=1 run), PMC summaries in place
 cp "$DST/${TAG}_pmc_env_step.json" "$DST/${TAG}_pmc_env_rollout.json" "$DST/${TAG}_pmc_sq.json" "$ROOT/profiles/"
 cd /tmp

@@ -174,15 +174,20 @@ def pmc_traffic(E, given, steps_per_launch=1):
     return None, None
 
 
-VALU_PEAK_WAVE_INST_PER_S = 1024 * 2.4e9 / 2     # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz
+# 256 CUs x 4 SIMDs, one wave64 vector instruction per 4 cycles at 2.4 GHz.  Four, not two: measured on this chip --
+# SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.03 quad-cycles per instruction in the fused ORCA kernel
+# (profiles/r02_pmc_sq.json), +4 cycles per v_max_i32 beside MFMAs (profiles/r02_mfma_issue.txt), and
+# MI355X_MICROARCH.md's issue-cost table (v_add_f32 / v_fma_f32: 4).  Only packed forms (v_pk_*_f32) retire two
+# float32 operations per lane in those 4 cycles, which is how the chip's 157 TFLOP/s vector peak is defined.
+VALU_PEAK_WAVE_INST_PER_S = 1024 * 2.4e9 / 4
 _SQ = None
 
 
 def valu_roofline(E, N, avg_ms, steps_per_launch, rollout, given=False):
     """Instruction-issue roofline of a kernel that HBM does not bound: VALU wave-instructions per env-step from the
     committed SQ_INSTS_VALU pass (profiles/rNN_pmc_sq.json) x env-steps per launch / the launch duration measured
-    live, against 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (float64 instructions occupy the pipe
-    for 4 cycles, so a float64-heavy kernel saturates below 1.0)."""
+    live, against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 vector instruction (float64 and transcendental
+    instructions occupy the pipe for 8, so a kernel heavy in those saturates below 1.0)."""
     global _SQ
     if _SQ is None:
         _SQ = {}
@@ -200,6 +205,9 @@ def valu_roofline(E, N, avg_ms, steps_per_launch, rollout, given=False):
             "unit": "G wave-instructions/s", "frac": round(ach / VALU_PEAK_WAVE_INST_PER_S, 4),
             "valu_wave_instructions_per_env_step": round(per_env_step, 2),
             "all_wave_instructions_per_env_step": round(k.get("insts_per_env_step", 0.0), 2),
+            "issue_cycles_per_valu_instruction": (round(4.0 * k["counters_per_launch"]["SQ_ACTIVE_INST_VALU"] /
+                                                        k["counters_per_launch"]["SQ_INSTS_VALU"], 2)
+                                                  if k.get("counters_per_launch", {}).get("SQ_ACTIVE_INST_VALU") else None),
             "wave_cycles_waiting_frac": k.get("wait_frac"), "avg_launch_us": round(avg_ms * 1e3, 3),
             "source": "SQ_INSTS_VALU etc. from %s (separate rocprofv3 --pmc pass), duration live" % fname}
 

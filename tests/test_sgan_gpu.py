@@ -34,7 +34,10 @@ def test_generator_matches_reference_fixture(tag, golden_dir):
         np.testing.assert_allclose(pr.cpu().numpy(), g[key + "pred_rel"], rtol=0, atol=TOL)
 
 
-@pytest.mark.parametrize("tag,E,N", [("p", 33, 5), ("p", 7, 10), ("np", 50, 5), ("p", 40, 1)])
+# pool-net cases: a scene inside one 16-pedestrian tile, straddling two, spanning several (N > 16); 1, 2 and 5 chunks
+# of five pedestrians per partner tile (full and ragged last chunk)
+@pytest.mark.parametrize("tag,E,N", [("p", 33, 5), ("p", 7, 10), ("np", 50, 5), ("p", 40, 1), ("p", 11, 3), ("p", 9, 7),
+                                     ("p", 4, 16), ("p", 3, 17), ("p", 2, 23), ("np", 3, 17)])
 def test_vec_world_ring_matches_oracle(tag, E, N, golden_dir):
     """VecSGANWorld over several consecutive calls (ring push / rounding / velocity conversion) against the
     torch-fp32 restatement fed with the equivalent explicit histories."""
@@ -94,3 +97,33 @@ def test_per_scene_pedestrian_counts(golden_dir):
             pr = pyref.sgan_generator(w, t32, r32, n, torch.from_numpy(noise[e:e + 1]), True)
             want = pyref.sgan_velocities(pr, t32[-1], 0.25).reshape(n, 2)
             np.testing.assert_allclose(got[e, :n], want, rtol=0, atol=4 * TOL)
+
+
+def test_full_size_step_on_sampled_scenes(golden_dir):
+    """BASELINE config 4's shape (4096 scenes x 10 pedestrians: 5 120 pool-net work units, i.e. every workgroup of the
+    persistent pool kernel walks its unit list twice) against the torch-fp32 restatement on a sample of the scenes
+    (scenes are independent of each other)."""
+    import torch
+    from modelcrowdnav_amd.policy.world_model import VecSGANWorld
+    g, gen = _gen(golden_dir, "p")
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(5)
+    E, N = 4096, 10
+    w = {k: v.detach().cpu() for k, v in gen.state_dict().items()}
+    world = VecSGANWorld(gen, E, N, dev, time_step=0.25)
+    pos = rng.uniform(-4, 4, (E, N, 2)); vel = rng.uniform(-0.8, 0.8, (E, N, 2))
+    world.init_constant_velocity(torch.from_numpy(pos).to(dev), torch.from_numpy(vel).to(dev))
+    frames = [np.around(pos - vel * 0.25 * k, 4) for k in range(7, -1, -1)]
+    sample = np.concatenate([np.arange(0, 8), rng.choice(E, 48, replace=False), np.arange(E - 8, E)])
+    for step in range(2):
+        pos = pos + vel * 0.25
+        noise = rng.normal(0, 1, (E, 8)).astype(np.float32)
+        got = world(torch.from_numpy(pos).to(dev), torch.from_numpy(noise).to(dev)).cpu().numpy()
+        frames = frames[1:] + [np.around(pos, 4)]
+        traj = np.stack([f[sample] for f in frames], 0).reshape(8, len(sample) * N, 2)
+        rel = np.zeros_like(traj); rel[1:] = traj[1:] - traj[:-1]
+        t32, r32 = torch.from_numpy(traj).float(), torch.from_numpy(rel).float()
+        pr = pyref.sgan_generator(w, t32, r32, N, torch.from_numpy(noise[sample]), True)
+        want = pyref.sgan_velocities(pr, t32[-1], 0.25).reshape(len(sample), N, 2)
+        np.testing.assert_allclose(got[sample], want, rtol=0, atol=4 * TOL)
+    assert np.isfinite(got).all()

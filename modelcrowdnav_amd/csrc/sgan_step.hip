@@ -90,7 +90,10 @@ __device__ __forceinline__ f32x4 tile_xy(float x, float y, int q)
 
 constexpr int kSganWaves = 4;
 
-__global__ __launch_bounds__(kSganWaves * 64) void sgan_encode_kernel(const SganParams p)
+#ifndef MCN_ENC_MINWAVES
+#define MCN_ENC_MINWAVES 1
+#endif
+__global__ __launch_bounds__(kSganWaves * 64, MCN_ENC_MINWAVES) void sgan_encode_kernel(const SganParams p)
 {
     // encoder weights resident in LDS (24 KiB): the 8 LSTM steps re-read them from there, registers stay few enough
     // for five wavefronts per SIMD, whose cell arithmetic (vector ALU) overlaps the other wavefronts' MFMAs
@@ -131,7 +134,9 @@ __global__ __launch_bounds__(kSganWaves * 64) void sgan_encode_kernel(const Sgan
         const float ry = t == 0 ? 0.0f : (float)(cur.y - prev.y);
         prev = cur; cur = nxt; lrx = rx; lry = ry;
         int ln = lane;
+#ifndef MCN_ENC_HOIST
         asm volatile("" : "+v"(ln));        // the LDS reads stay inside the loop (hoisted, they pin 100 registers)
+#endif
         f32x4 cat[3] = {tile_xy(rx, ry, q), h[0], h[1]};
         f32x4 g[8];
         dense_lds<3, 8, false, 1>(cat, g, s_wl, s_bl, ln);

@@ -116,6 +116,9 @@ typedef struct mcn_roll_rec {
 typedef struct mcn_rollout {
     /* discounted return: sum_t disc_table[t] * r_t, disc_table[t] = pow(gamma, t*dt*v_pref) (explorer.py:124) */
     const double *disc_table;  int32_t disc_len;
+    /* the "too close" statistics (danger_count / danger_dist_sum, explorer.py:88-90,138-141) only count steps of an env's
+     * first `danger_episodes` episodes; 0 = every step (see danger_short_from below) */
+    int32_t danger_episodes;
     mcn_roll_rec *state;       /* [E], or NULL: no return accounting */
     /* records of finished episodes: with fin_slots == 1 slot 0 holds the latest episode of env e; with
      * fin_slots > 1 episode number k < fin_slots of env e lands in slot k and later ones are not recorded */
@@ -123,6 +126,9 @@ typedef struct mcn_rollout {
     double  *fin_time;         /* [fin_slots][E] env.global_time at the end (explorer.py:95,99) */
     uint8_t *fin_info;         /* [fin_slots][E] */
     int32_t  fin_slots;        /* >= 1 */
+    /* k episodes over E envs leave the last round partial: when danger_short_from > 0, envs with index >=
+     * danger_short_from - 1 count one episode fewer than danger_episodes; 0 = all envs count danger_episodes */
+    int32_t  danger_short_from;
     /* auto-reset from a pool of host-generated scenarios (bit-exact CrowdSim.reset output) */
     const double *pool_hpos, *pool_hgoal;                /* [P*N][2] */
     const double *pool_hrad, *pool_hvpref;               /* [P*N]    */

@@ -71,9 +71,9 @@ def roll_rec_views(state):
 
 class Rollout(C.Structure):
     _fields_ = [
-        ("disc_table", _vp), ("disc_len", _i),
+        ("disc_table", _vp), ("disc_len", _i), ("danger_episodes", _i),
         ("state", _vp),
-        ("fin_return", _vp), ("fin_time", _vp), ("fin_info", _vp), ("fin_slots", _i),
+        ("fin_return", _vp), ("fin_time", _vp), ("fin_info", _vp), ("fin_slots", _i), ("danger_short_from", _i),
         ("pool_hpos", _vp), ("pool_hgoal", _vp), ("pool_hrad", _vp), ("pool_hvpref", _vp), ("pool_hvel", _vp),
         ("pool_size", _i), ("case_stride", _i),
         ("robot_start", _d * 2), ("robot_goal", _d * 2), ("robot_theta0", _d),

@@ -139,7 +139,10 @@ __global__ __launch_bounds__(256) void env_pair_kernel(const StepParams p)
         case_g = next_case;
         const int di = ep_steps < ro.disc_len ? ep_steps : ro.disc_len - 1;
         const double ep_disc = s_disc[wave][di];
-        if (inf == MCN_INFO_DANGER) { danger_count += 1; danger_sum += dmin; }
+        if (inf == MCN_INFO_DANGER && (ro.danger_episodes <= 0 ||
+            fin_count < ro.danger_episodes - ((ro.danger_short_from > 0 && e >= ro.danger_short_from - 1) ? 1 : 0))) {
+            danger_count += 1; danger_sum += dmin;
+        }
         const double ret = ep_return + ep_disc * rew;
         if (dn) {
             if (active && h == 0) {

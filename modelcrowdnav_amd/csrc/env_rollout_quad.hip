@@ -277,7 +277,12 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
             //      record with selects; only the finished-episode stores are the lead lane's ----
             case_g = rs.next_case;
             if (has_state) {
-                const bool danger = inf == MCN_INFO_DANGER;
+                bool danger = inf == MCN_INFO_DANGER;
+                if (danger) {                       // (uncommon step: the limit is re-read from the kernel arguments)
+                    const KernargPtr kp = kernarg_here();
+                    const int lim = kp->roll.danger_episodes, sf = kp->roll.danger_short_from;
+                    danger = lim <= 0 || rs.fin_count < lim - ((sf > 0 && e >= sf - 1) ? 1 : 0);
+                }
                 rs.danger_count += danger ? 1 : 0;
                 rs.danger_dist_sum = danger ? rs.danger_dist_sum + dmin : rs.danger_dist_sum;
                 const double ret = rs.ep_return + ep_disc * rew;

@@ -355,7 +355,10 @@ void env_step_kernel(const StepParams p)
         if (p.has_roll) {
             const mcn_rollout &r = p.roll;
             if (r.state) {
-                if (inf == MCN_INFO_DANGER) { rs.danger_count += 1; rs.danger_dist_sum += dmin; }
+                if (inf == MCN_INFO_DANGER && (r.danger_episodes <= 0 ||
+            rs.fin_count < r.danger_episodes - ((r.danger_short_from > 0 && e >= r.danger_short_from - 1) ? 1 : 0))) {
+                    rs.danger_count += 1; rs.danger_dist_sum += dmin;
+                }
                 const double ret = rs.ep_return + ep_disc * rew;
                 if (dn) {
                     const int k = rs.fin_count;

@@ -200,7 +200,10 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void env_step_quad_kernel(const S
         if (p.has_roll) {
             const mcn_rollout &ro = p.roll;
             if (ro.state) {
-                if (inf == MCN_INFO_DANGER) { rs.danger_count += 1; rs.danger_dist_sum += dmin; }
+                if (inf == MCN_INFO_DANGER && (ro.danger_episodes <= 0 ||
+            rs.fin_count < ro.danger_episodes - ((ro.danger_short_from > 0 && e >= ro.danger_short_from - 1) ? 1 : 0))) {
+                    rs.danger_count += 1; rs.danger_dist_sum += dmin;
+                }
                 const double ret = rs.ep_return + ep_disc * rew;
                 if (dn) {
                     const int k = rs.fin_count;

@@ -43,13 +43,15 @@ def shard(total, rank, world_size):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_records(returns, infos, times, counts=None):
+def gather_records(returns, infos, times, counts=None, extras=()):
     """One collective: all ranks contribute [n_local] episode records and receive the
-    concatenation in rank order.  returns/times float64, infos uint8/int; all on the same device."""
+    concatenation in rank order.  returns/times float64, infos uint8/int; all on the same device.
+    `extras`: further per-record float64 columns that ride in the same collective (returned as res["extras"])."""
     n = returns.numel()
     cols = [returns.reshape(-1).double(), infos.reshape(-1).double(), times.reshape(-1).double()]
     if counts is not None:
         cols.append(counts.reshape(-1).double())
+    cols += [x.reshape(-1).double() for x in extras]
     packed = torch.stack(cols, 1).contiguous()
     rank, ws = world()
     home = packed.device
@@ -79,4 +81,6 @@ def gather_records(returns, infos, times, counts=None):
     res = {"return": out[:, 0], "info": out[:, 1].to(torch.uint8), "time": out[:, 2]}
     if counts is not None:
         res["count"] = out[:, 3].to(torch.int32)
+    first = 4 if counts is not None else 3
+    res["extras"] = [out[:, first + i] for i in range(len(extras))]
     return res

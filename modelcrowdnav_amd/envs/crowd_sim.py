@@ -308,9 +308,12 @@ class VecCrowdSim(object):
             self.count_hh = keep
 
     # ---------------------------------------------------------------- fused rollout bookkeeping
-    def attach_rollout(self, gamma, pool=None, case_stride=1, first_cases=None, fin_slots=1):
+    def attach_rollout(self, gamma, pool=None, case_stride=1, first_cases=None, fin_slots=1, danger_episodes=0,
+                       danger_short_from=0):
         """Enable Explorer-style return accounting (explorer.py:124) and, when `pool` ([P,N,9]
-        host scenarios) is given, in-kernel auto-reset from that HBM-resident pool."""
+        host scenarios) is given, in-kernel auto-reset from that HBM-resident pool.  `danger_episodes` > 0: the
+        "too close" counters (explorer.py:88-90) only cover each env's first that many episodes (one fewer for envs
+        from index `danger_short_from - 1` on, when that is > 0: the partial last round of k episodes over E envs)."""
         E, dev = self.num_envs, self.device
         horizon = int(round(self.time_limit / self.time_step)) + 2
         v_pref = float(self.robot.v_pref)
@@ -325,6 +328,7 @@ class VecCrowdSim(object):
         t["fin_info"] = torch.zeros(fin_slots, E, dtype=torch.uint8, device=dev)
         r = _hip.Rollout()
         r.disc_table, r.disc_len, r.fin_slots = _hip.ptr(t["disc"]), horizon, int(fin_slots)
+        r.danger_episodes, r.danger_short_from = int(danger_episodes), int(danger_short_from)
         for k in ("state", "fin_return", "fin_time", "fin_info"):
             setattr(r, k, _hip.ptr(t[k]))
         if pool is not None:

@@ -169,8 +169,12 @@ class VecExplorer(object):
         # at least two finished-episode slots: with one the kernel keeps the LATEST episode of an env (mcn.h), and an env
         # that finishes early keeps replaying its case until the slowest env is done -- with a stochastic robot
         # (epsilon-greedy, random action_fn) the record would then describe the last repeat instead of the first run
+        # the "too close" counters cover exactly the k episodes: env g (global) plays `rounds` of them if
+        # (rounds - 1) * E_total + g < k, else one fewer
+        n_full = min(max(k - (rounds - 1) * E_total - lo, 0), E_local)
         bufs = env.attach_rollout(self.gamma, pool=pool, case_stride=stride,
-                                  first_cases=(mine[:, 1] if rounds > 1 else mine[:, 0]), fin_slots=max(rounds, 2))
+                                  first_cases=(mine[:, 1] if rounds > 1 else mine[:, 0]), fin_slots=max(rounds, 2),
+                                  danger_episodes=rounds, danger_short_from=(0 if n_full == E_local else n_full + 1))
         horizon = int(round(env.time_limit / env.time_step)) + 2
         limit = max_steps if max_steps is not None else rounds * horizon
         if update_memory and (self.memory is None or self.gamma is None):
@@ -236,8 +240,11 @@ class VecExplorer(object):
                                  torch.stack(col_i).cpu().numpy(), k, rounds, E_total, update_raw_ob, cacheFile)
         env.case_counter[phase] = (first + k) % size
         # records in global episode order: episode g = r * E_total + global_env
+        # (the envs' "too close" counters ride in the same collective, in the rows of their first episode)
+        dng = torch.zeros(2, E_local, rounds, dtype=torch.float64, device=bufs["fin_return"].device)
+        dng[0, :, 0], dng[1, :, 0] = bufs["danger_count"].double(), bufs["danger_dist_sum"]
         rec = mdist.gather_records(bufs["fin_return"][:rounds].t().contiguous(), bufs["fin_info"][:rounds].t().contiguous(),
-                                   bufs["fin_time"][:rounds].t().contiguous())
+                                   bufs["fin_time"][:rounds].t().contiguous(), extras=(dng[0], dng[1]))
         ret = rec["return"].view(-1, rounds).cpu().numpy()        # [E_total, rounds]
         inf = rec["info"].view(-1, rounds).cpu().numpy()
         tim = rec["time"].view(-1, rounds).cpu().numpy()
@@ -257,8 +264,14 @@ class VecExplorer(object):
         if print_failure:
             logging.info("Collision cases: %s", " ".join(str(i) for i, c in enumerate(infos) if c == _hip.INFO_COLLISION))
             logging.info("Timeout cases: %s", " ".join(str(i) for i, c in enumerate(infos) if c == _hip.INFO_TIMEOUT))
-        self.last_records = dict(returns=returns, infos=infos, times=times,
-                                 danger_steps=int(bufs["danger_count"].sum().item()))
+        # "too close" statistics of the k episodes (explorer.py:88-90,138-141)
+        too_close, dist_sum = int(round(rec["extras"][0].sum().item())), float(rec["extras"][1].sum().item())
+        if phase in ("val", "test"):
+            num_step = sum(times) / env.time_step
+            logging.info("Frequency of being in danger: %.2f and average min separate distance in danger: %.2f",
+                         too_close / num_step, dist_sum / too_close if too_close else 0.0)
+        self.last_records = dict(returns=returns, infos=infos, times=times, danger_steps=too_close,
+                                 danger_dist_sum=dist_sum)
         env.detach_rollout()
         if returnRate and returnNav:
             return average(returns), success / k, collision / k, (k - success - collision) / k, avg_nav_time

@@ -33,7 +33,8 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(_hip.RollRec) == 32 and _hip.RollRec.fin_count.offset == 12
     assert _hip.RollRec.danger_dist_sum.offset == 24
     r = _hip.Rollout
-    assert r.disc_len.offset == 8 and r.state.offset == 16 and r.fin_slots.offset == 48
+    assert r.disc_len.offset == 8 and r.danger_episodes.offset == 12 and r.state.offset == 16
+    assert r.fin_slots.offset == 48 and r.danger_short_from.offset == 52
     assert r.pool_hpos.offset == 56 and r.pool_size.offset == 96 and r.case_stride.offset == 100
     assert r.robot_start.offset == 104 and ctypes.sizeof(r) == 144
 

@@ -26,17 +26,20 @@ def _oracle_episode(scen, gamma=0.9):
     st.hr[0], st.hvpref[0] = scen[:, 7], scen[:, 8]
     st.rpy[0], st.rgy[0], st.rr[0] = -4.0, 4.0, 0.3
     cfg = cport.default_cfg()
-    rewards = []
+    rewards, too_close, min_dist = [], 0, 0.0
     while True:
         dx, dy = st.rgx[0] - st.rpx[0], st.rgy[0] - st.rpy[0]
         ax = 0.6 if dx > 0.2 else (-0.6 if dx < -0.2 else 0.0)
         ay = 0.6 if dy > 0.2 else (-0.6 if dy < -0.2 else 0.0)
         out = cport.env_step(cfg, st, np.array([ax]), np.array([ay]))
         rewards.append(float(out["reward"][0]))
+        if out["info"][0] == cport.INFO_DANGER:                      # explorer.py:88-90
+            too_close += 1
+            min_dist += float(out["dmin"][0])
         if out["done"][0]:
             tm = 25.0 if out["info"][0] == cport.INFO_TIMEOUT else float(st.gtime[0])
             ret = sum([pow(gamma, t * 0.25 * 1.0) * r for t, r in enumerate(rewards)])
-            return ret, int(out["info"][0]), tm
+            return ret, int(out["info"][0]), tm, too_close, min_dist
 
 
 def test_vec_explorer_equals_sequential_loop():
@@ -56,6 +59,10 @@ def test_vec_explorer_equals_sequential_loop():
     assert avg == sum([w[0] for w in want]) / k
     assert len(set(got["infos"])) > 1, "test should exercise more than one outcome"
     assert env.case_counter["test"] == k % 500
+    # the "too close" statistics cover exactly the k episodes (k = 70 over 32 envs: 6 envs play three, 26 play two,
+    # and every env keeps stepping until the slowest one is done)
+    assert got["danger_steps"] == sum(w[3] for w in want) > 0
+    assert abs(got["danger_dist_sum"] - sum(w[4] for w in want)) < 1e-9
 
 
 def test_vec_explorer_action_sequence_uses_fused_rollout():
@@ -77,8 +84,9 @@ def test_vec_explorer_action_sequence_uses_fused_rollout():
             out = ex.run_k_episodes(k, "val", action_fn=lambda env_, t: seq[t])
         recs.append((out, ex.last_records))
     assert recs[0][0] == recs[1][0]
-    for key in ("returns", "infos", "times"):
+    for key in ("returns", "infos", "times", "danger_steps"):
         assert recs[0][1][key] == recs[1][1][key], key
+    assert abs(recs[0][1]["danger_dist_sum"] - recs[1][1]["danger_dist_sum"]) < 1e-9 and recs[0][1]["danger_steps"] > 0
     assert len(set(recs[0][1]["infos"])) > 1
 
 

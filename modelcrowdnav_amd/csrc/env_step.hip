@@ -24,6 +24,7 @@
 #include "../../include/mcn.h"
 #include "orca_device.hpp"
 #include "orca_static.hpp"
+#include "orca_coop.hpp"
 #include "env_step_params.hpp"
 #include "env_common.hpp"
 
@@ -153,9 +154,17 @@ void env_step_kernel(const StepParams p)
     double hax = 0, hay = 0;
     int hh_pre = 0;                 // static-N ORCA kernels pre-filter the human-human overlaps while they hold the
     bool border_pre = false;        // squared distances
+    // Dense crowds (>= 5 candidate neighbours) in a latency-bound batch (one wavefront per workgroup): the 3-D LP of the
+    // few lanes that need it is solved by the whole wavefront (orca_coop.hpp) instead of running its unrolled O(n^3)
+    // code for one or two active lanes.  Throughput-bound batches (BLOCK = 256) keep the unrolled form.
+    constexpr int NCK = NT > 0 ? NT - 1 + VIS : 0;
+    constexpr int NLK = NCK > 0 ? NCK : 1;
+    constexpr bool kCoopLp3 = (MODE == MCN_HUMANS_ORCA) && NT > 0 && NCK >= 5 && BLOCK == 64;
+    float4 Lk[kCoopLp3 ? NLK : 1];
+    int lp_nl = 0, lp_fail = 0;
+    float ox = 0, oy = 0;
     if (active) {
         if constexpr (MODE == MCN_HUMANS_ORCA) {
-            float ox, oy;
             if constexpr (NT > 0) {
                 constexpr int NC = NT - 1 + VIS;
                 // Each pair of humans builds its half-plane ONCE: the two humans' lines are (v + u/2, dir) and
@@ -216,8 +225,15 @@ void env_step_kernel(const StepParams p)
                     const float ddx = fpx - rq.x, ddy = fpy - rq.y;
                     dd[NC - 1] = dot2(ddx, ddy, ddx, ddy);
                 }
-                orca_solve_static_lines<NC>(Lnat, dd, (float)attr.y, (float)(goal.x - pos.x), (float)(goal.y - pos.y),
-                                            c.orca_neighbor_dist, c.orca_max_neighbors, ox, oy);
+                if constexpr (kCoopLp3) {
+                    orca_sort_lp2<NC>(Lnat, dd, (float)attr.y, (float)(goal.x - pos.x), (float)(goal.y - pos.y),
+                                      c.orca_neighbor_dist, c.orca_max_neighbors, ox, oy, lp_fail, lp_nl);
+#pragma unroll
+                    for (int k2 = 0; k2 < NLK; ++k2) Lk[k2] = Lnat[k2];        // the wavefront finishes them together below
+                } else {
+                    orca_solve_static_lines<NC>(Lnat, dd, (float)attr.y, (float)(goal.x - pos.x), (float)(goal.y - pos.y),
+                                                c.orca_neighbor_dist, c.orca_max_neighbors, ox, oy);
+                }
             } else {
                 GroupCand cand{sAgF, sRadF, make_float4(0, 0, 0, 0), 0.f, gbase, h, N - 1};
                 int ncand = N - 1;
@@ -227,7 +243,7 @@ void env_step_kernel(const StepParams p)
                            (float)(goal.x - pos.x), (float)(goal.y - pos.y),
                            c.orca_neighbor_dist, c.orca_max_neighbors, c.orca_time_horizon, (float)dt, L, ox, oy);
             }
-            hax = (double)ox; hay = (double)oy;
+            if constexpr (!kCoopLp3) { hax = (double)ox; hay = (double)oy; }
         } else if constexpr (MODE == MCN_HUMANS_LINEAR) {
             const double th = atan2(goal.y - pos.y, goal.x - pos.x);
             hax = cos(th) * attr.y; hay = sin(th) * attr.y;
@@ -235,6 +251,12 @@ void env_step_kernel(const StepParams p)
             const double2 gv = reinterpret_cast<const double2 *>(p.given_v)[a];
             hax = gv.x; hay = gv.y;
         }
+    }
+
+    if constexpr (kCoopLp3) {
+        CoopLds &coop = reinterpret_cast<CoopLds *>(sRobRadF + BLOCK)[wave];
+        lp3_wave_coop<NLK>(coop, Lk, lp_nl, lp_fail, (float)attr.y, ox, oy);      // every lane of the wavefront
+        hax = (double)ox; hay = (double)oy;
     }
 
     // ---- K2: swept-circle distance to the robot, overlap with later humans ----
@@ -394,8 +416,10 @@ void env_step_kernel(const StepParams p)
     }
 }
 
-static size_t step_smem_bytes(int block, int nl_cap)
+static size_t step_smem_bytes(int block, int nl_cap, bool coop = false)
 {
+    if (coop)   // + one CoopLds per wavefront (16-byte aligned: every array before it is a multiple of 16 B per lane x 64)
+        return step_smem_bytes(block, nl_cap) + (size_t)(block / 64) * sizeof(CoopLds);
     // float4 lines + float4 sAgF + double2 sPosD + double2 sRobPos + double2 sRobAct + float4 sRobF
     // + double sRadD + double sRobRad + float sRadF + float sRobRadF
     return (size_t)block * (16u * nl_cap + 16 + 16 + 16 + 16 + 16 + 8 + 8 + 4 + 4);
@@ -404,7 +428,8 @@ static size_t step_smem_bytes(int block, int nl_cap)
 template <int BLOCK, int NT, int VIS, int MODE, int HH_T>
 static void launch_one(const StepParams &p, int blocks, hipStream_t stream)
 {
-    const size_t sm = step_smem_bytes(BLOCK, MODE != MCN_HUMANS_ORCA ? 0 : (NT ? NT / 2 : p.nl_cap));
+    const size_t sm = step_smem_bytes(BLOCK, MODE != MCN_HUMANS_ORCA ? 0 : (NT ? NT / 2 : p.nl_cap),
+                                      MODE == MCN_HUMANS_ORCA && NT > 0 && NT - 1 + VIS >= 5 && BLOCK == 64);
     hipLaunchKernelGGL((env_step_kernel<BLOCK, NT, VIS, MODE, HH_T>), dim3(blocks), dim3(BLOCK), sm, stream, p);
 }
 

@@ -298,15 +298,18 @@ __device__ __forceinline__ void orca_solve_static(float4 (&cpv)[NC > 0 ? NC : 1]
 // The same solve from half-planes built elsewhere: Lnat[c] is candidate c's half-plane (insertion order), dd[c] its
 // squared distance.  Sorting the finished lines by distance instead of the candidates before building them gives the
 // same lines in the same order (stable network, same keys).
+// First half: sort + 2-D LP.  On return Lnat is sorted, nl is the line count, (rx, ry) the 2-D LP's result and `fail`
+// the first line it could not satisfy (== nl when it succeeded); the caller finishes with the 3-D LP (lp3_static
+// below, or lp3_wave_coop in orca_coop.hpp).
 template <int NC>
-__device__ __forceinline__ void orca_solve_static_lines(float4 (&Lnat)[NC > 0 ? NC : 1], float (&dd)[NC > 0 ? NC : 1],
-                                                        float max_speed, float prefx, float prefy, float neighbor_dist,
-                                                        int max_neighbors, float &outx, float &outy)
+__device__ __forceinline__ void orca_sort_lp2(float4 (&Lnat)[NC > 0 ? NC : 1], float (&dd)[NC > 0 ? NC : 1],
+                                              float max_speed, float prefx, float prefy, float neighbor_dist,
+                                              int max_neighbors, float &rx, float &ry, int &fail, int &nl)
 {
-    constexpr int NL = NC < kMaxLines ? (NC > 0 ? NC : 1) : kMaxLines;
+    constexpr int NL = NC > 0 ? NC : 1;
     static_assert(NC <= kMaxLines, "more candidates than line slots: the tail of the sorted list would be lost");
     const float range_sq = neighbor_dist * neighbor_dist;
-    float d[NC > 0 ? NC : 1];
+    float d[NL];
     int nin = 0;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -325,23 +328,35 @@ __device__ __forceinline__ void orca_solve_static_lines(float4 (&Lnat)[NC > 0 ? 
             Lnat[j]     = make_float4(sw ? a.x : b.x, sw ? a.y : b.y, sw ? a.z : b.z, sw ? a.w : b.w);
         }
     }
-    int nl = nin < max_neighbors ? nin : max_neighbors;
+    nl = nin < max_neighbors ? nin : max_neighbors;
     if (nl > NL) nl = NL;
-    float4 (&L)[NL] = reinterpret_cast<float4 (&)[NL]>(Lnat);
-    float rx, ry;
     if (dot2(prefx, prefy, prefx, prefy) > max_speed * max_speed) {
         const float inv = 1.0f / sqrtf(dot2(prefx, prefy, prefx, prefy));
         rx = max_speed * (prefx * inv); ry = max_speed * (prefy * inv);
     } else {
         rx = prefx; ry = prefy;
     }
-    int fail = nl;
-    Lp2Step<0, NL>::run(L, nl, max_speed, prefx, prefy, rx, ry, fail);
+    fail = nl;
+    Lp2Step<0, NL>::run(Lnat, nl, max_speed, prefx, prefy, rx, ry, fail);
+}
+
+template <int NL>
+__device__ __forceinline__ void lp3_static(const float4 (&L)[NL], int nl, int fail, float max_speed, float &rx, float &ry)
+{
     if (fail < nl) {
         float dist = 0.0f;
         Lp3Step<0, NL>::run(L, nl, fail, max_speed, rx, ry, dist);
     }
-    outx = rx; outy = ry;
+}
+
+template <int NC>
+__device__ __forceinline__ void orca_solve_static_lines(float4 (&Lnat)[NC > 0 ? NC : 1], float (&dd)[NC > 0 ? NC : 1],
+                                                        float max_speed, float prefx, float prefy, float neighbor_dist,
+                                                        int max_neighbors, float &outx, float &outy)
+{
+    int nl, fail;
+    orca_sort_lp2<NC>(Lnat, dd, max_speed, prefx, prefy, neighbor_dist, max_neighbors, outx, outy, fail, nl);
+    lp3_static<(NC > 0 ? NC : 1)>(Lnat, nl, fail, max_speed, outx, outy);
 }
 
 }  // namespace mcn

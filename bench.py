@@ -260,7 +260,7 @@ def _timed(fn, iters):
 
 
 def extra_configs(device):
-    """BASELINE configs[2] and [3], same batch shape, reported next to the headline workload."""
+    """BASELINE configs[2], [3] and the per-GPU shard of [4], reported next to the headline workload."""
     out = []
     # ---- config 3: 4096 envs x 5 humans, SARL attention value-net robot ----
     E, N = 4096, 5
@@ -320,6 +320,18 @@ def extra_configs(device):
                     # are folded into the layers they feed (sgan_step.hip); `executed_*` counts the MFMAs really issued
                     # (per 16 pedestrians: encoder 576, pool 2 x 1 064, decoder 160; 2 048 FLOP each).
                     "roofline": _sgan_roofline(E, N, ms_sgan)})
+        del env
+    # ---- config 5's per-GPU shard: 4096 envs x 10 humans, ORCA humans, random robot actions ----
+    # (BASELINE configs[4] = 32 768 x 10 over 8 GPUs; crowds above 5 humans have no fused multi-step kernel: one
+    # mcn_env_step launch per step, replayed from a hipGraph)
+    E, N = 4096, 10
+    env, _ = build_env(E, N, 0, device)
+    acts10 = make_actions(64, E, E, 0, device)
+    ms10, _best = time_kernel_events(env, acts10, 200)
+    out.append({"config": "4096 envs x 10 humans per GPU (the shard of BASELINE's 32 768 x 10 on 8 GPUs), ORCA humans, "
+                          "random robot actions, one mcn_env_step launch per step",
+                "ms_per_step": round(ms10, 5), "env_steps_per_sec": round(E / ms10 * 1e3, 1),
+                "roofline": roofline_entry(E, N, ms10)})
     return out
 
 

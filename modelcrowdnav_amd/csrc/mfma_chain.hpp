@@ -31,7 +31,6 @@ __device__ __forceinline__ void dense(const f32x4 (&in)[KT], f32x4 (&out)[NT], c
 {
 #pragma unroll
     for (int n = 0; n < NT; n += 2) {
-        constexpr int dummy = 0; (void)dummy;
         const bool two = (n + 1 < NT);
         f32x4 a0, a1 = {0, 0, 0, 0};
         { const float4 b = bf[n * 64 + lane]; a0 = (f32x4){b.x, b.y, b.z, b.w}; }

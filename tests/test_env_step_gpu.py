@@ -279,6 +279,29 @@ def test_rollout_launch_equals_single_steps(N, visible, with_pool, split, tuning
         assert np.array_equal(sc[k].view(np.uint8), sb[k].view(np.uint8)), k
 
 
+@pytest.mark.parametrize("N,visible", [(10, False), (7, True), (6, False)])
+def test_rollout_entry_point_with_larger_crowds(N, visible):
+    """mcn_env_rollout for crowds the fused launch does not cover (more than 4 ORCA neighbours per human): the entry
+    point runs its T single-step launches (the wavefront-cooperative 3-D LP of one-wavefront workgroups included) and
+    must leave every byte as T mcn_env_step calls do; and both equal the oracle's trajectory."""
+    torch = _torch()
+    E, T = 300, 110
+    rng = np.random.RandomState(N)
+    sp, aa = rng.uniform(0, 1, (T, E)), rng.uniform(0, 2 * np.pi, (T, E))
+    acts = torch.from_numpy(np.stack([sp * np.cos(aa), sp * np.sin(aa)], -1))
+    a = _rollout_env(E, N, visible, True, fin_slots=2)
+    b = _rollout_env(E, N, visible, True, fin_slots=2)
+    acts_d = acts.to(a.device)
+    a.rollout(acts_d[:30]); a.rollout(acts_d[30:])
+    for t in range(T):
+        b.step(acts_d[t])
+    torch.cuda.synchronize()
+    sa, sb = _snapshot(a), _snapshot(b)
+    for k in sa:
+        assert np.array_equal(sa[k].view(np.uint8), sb[k].view(np.uint8)), k
+    assert int(a.rollout_buffers["fin_count"].min().item()) >= 1
+
+
 @pytest.mark.parametrize("split", ["0", "1"])
 def test_rollout_launch_unicycle_robot(split, tuning):
     """The (v, r) robot (float64 sin / cos on the device, agent.py:110-135) through the fused launch: same code as the

@@ -6,8 +6,8 @@ What is checked instead, on thousands of random configurations:
   * optimality   -- when the 2-D LP is feasible, no candidate of an exhaustive active-set
                     enumeration (pref itself, projections on each line / the disc, all line-line
                     and line-disc intersections) is feasible and closer to the preferred velocity
-  * fallback     -- when infeasible, the result's maximum penetration is within tolerance of the
-                    minimum found by a dense search
+  * fallback     -- the infeasible case (linearProgram3) and the half-plane construction itself are pinned
+                    against independent computations in tests/test_orca_pins.py
   * analytic     -- no neighbours / far neighbours -> clip(pref); mirrored head-on pair ->
                     mirrored velocities; half-plane geometry of a single static neighbour
 """
@@ -62,7 +62,7 @@ def _random_case(rng, n_other, crowded):
 
 def test_feasible_and_optimal_against_active_set_enumeration():
     rng = np.random.RandomState(42)
-    n_feasible = n_infeasible = n_illcond = 0
+    n_feasible = n_infeasible = 0
     for it in range(1200):
         n_other = int(rng.randint(1, 10))
         pos, vel, rad, ms, pref, opos, ovel, orad = _random_case(rng, n_other, crowded=(it % 3 == 0))
@@ -77,20 +77,8 @@ def test_feasible_and_optimal_against_active_set_enumeration():
             assert _viol(lines, v) <= EPS, (it, _viol(lines, v))
             assert np.linalg.norm(v - pref) <= best + 5e-4, (it, np.linalg.norm(v - pref), best)
         else:
-            n_infeasible += 1
-            if np.linalg.norm(v) > ms * (1 + 1e-3):
-                # The 3-D LP intersects near-parallel half-planes far from the origin; in float32 the
-                # disc test dp^2 + r^2 - |p|^2 then cancels catastrophically.  This is a property of the
-                # published float32 algorithm, kept as is; it must stay rare.
-                n_illcond += 1
-                continue
-            ang = np.linspace(0, 2 * np.pi, 181)[:-1]
-            rr = np.linspace(0, ms, 41)
-            grid = np.array([[r * np.cos(a), r * np.sin(a)] for r in rr for a in ang])
-            gmin = min(_viol(lines, g) for g in grid)
-            assert _viol(lines, v) <= gmin + 0.05, (it, _viol(lines, v), gmin)
+            n_infeasible += 1      # the 3-D LP: pinned against SLSQP in tests/test_orca_pins.py
     assert n_feasible > 600 and n_infeasible > 8, (n_feasible, n_infeasible)
-    assert n_illcond <= 0.1 * n_infeasible, (n_illcond, n_infeasible)
 
 
 def test_analytic_cases():

@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--replays", type=int, default=0,
                     help="passes of the K steps inside the timed region (0 = as many as fill --min-timed-ms)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the N > 1 branches (process group, the one all_gather of episode records, the MAX / SUM "
+                         "all-reduces) with a single rank too: exercises RCCL on a one-GPU box")
     ap.add_argument("--min-timed-ms", type=float, default=20.0,
                     help="the one-off costs of a timed region (sync, the final gather with several ranks) stay below ~2 %% of it")
     return ap.parse_args()
@@ -133,76 +136,156 @@ def pairwise_bytes_per_env_step(N):
 
 
 _PMC = None
+_MODES = {0: "orca", 1: "linear", 2: "given"}          # include/mcn.h: MCN_HUMANS_*
+
+
+def classify_kernel(name, run_humans=None):
+    """(family, humans, mode, lanes per human) of an mcn:: kernel from its name and template arguments -- never from
+    a substring guess: env_step_kernel<BLOCK, NT, VIS, MODE, HH>; env_pair_kernel<N> (given velocities by
+    construction); env_step_quad_kernel<NT, VIS, SPLIT>; env_rollout_quad_kernel<NT, VIS, UNI, SPLIT>.  Network
+    kernels (sarl_value_kernel, sgan_*_kernel) have no mode."""
+    import re
+    m = re.search(r"mcn::(\w+)(?:<([^>]*)>)?", name)
+    if not m:
+        return None
+    fam = m.group(1)
+    args = [x.strip() for x in (m.group(2) or "").split(",") if x.strip()]
+    if fam == "env_pair_kernel":
+        return fam, int(args[0]), "given", 1
+    if fam == "env_step_kernel":
+        return fam, (int(args[1]) or run_humans), _MODES[int(args[3])], 1
+    if fam == "env_step_quad_kernel":
+        return fam, int(args[0]), "orca", 8 if args[2] == "true" else 4
+    if fam == "env_rollout_quad_kernel":
+        return fam, int(args[0]), "orca", 8 if args[3] == "true" else 4
+    return fam, run_humans, None, None
+
+
+def expected_kernel(E, N, given, steps_per_launch=1):
+    """The kernel family the library's dispatcher picks for this launch (csrc/mcn_api.hip fill_step_params,
+    env_step.hip launch_env_step, automatic tuning)."""
+    if steps_per_launch > 1:
+        return "env_rollout_quad_kernel"
+    waves = -(-E // (64 // N))
+    if given:
+        return "env_pair_kernel" if (waves > 4096 and N in (5, 10)) else "env_step_kernel"
+    if N - 1 <= 4 and -(-E // (64 // (4 * N))) <= 2800:
+        return "env_step_quad_kernel"
+    return "env_step_kernel"
 
 
 def _profiles(pattern):
-    """Committed PMC summaries, oldest round first (later rounds override earlier ones)."""
+    """Committed summaries of the LATEST round that has any (profiles/rNN_<pattern>): numbers of an earlier round
+    describe another build's kernels and are never mixed in."""
     import glob
+    import re
+    files = glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + pattern))
+    if not files:
+        return []
+    last = max(re.match(r"r(\d\d)_", os.path.basename(f)).group(1) for f in files)
     out = []
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
-        try:
-            out.append((os.path.basename(f), json.load(open(f))))
-        except Exception:
-            pass
+    for f in sorted(files):
+        if os.path.basename(f).startswith("r%s_" % last):
+            try:
+                out.append((os.path.basename(f), json.load(open(f))))
+            except Exception:
+                pass
     return out
 
 
-def pmc_traffic(E, given, steps_per_launch=1):
+def pmc_traffic(E, given, steps_per_launch=1, N=5):
     """HBM bytes per launch from the committed PMC summaries (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-    passes, gfx950 FETCH_SIZE x2 correction; profiles/rNN_pmc_env_step.json, rNN_pmc_env_rollout.json).
-    Returns (bytes, source): an exact (kernel kind, envs, steps per launch) match of the latest round, else for the
-    rollout kernel -- whose traffic is affine in the steps per launch (state once + one action per step) -- the
-    line through the two nearest measured launch lengths, else (None, None)."""
+    passes, gfx950 FETCH_SIZE x2 correction; profiles/rNN_pmc_env_step.json, rNN_pmc_env_rollout.json) of the latest
+    round.  A hit must be the SAME kernel family the dispatcher runs for this launch, the same human-policy mode,
+    humans, envs and steps per launch; for the rollout kernel -- whose traffic is affine in the steps per launch
+    (state once + one action row per step) -- the line through the two nearest measured launch lengths also counts.
+    Returns (bytes, source, kernel name) or (None, None, None)."""
     global _PMC
     if _PMC is None:
         _PMC = {}
-        for fname, d in _profiles("r*_pmc_env_*.json"):
+        for fname, d in _profiles("pmc_env_*.json"):
             for k in d.get("kernels", []):
-                key = (k["envs"], "pairwise-only" in k["what"], int(k.get("steps_per_launch", 1)), "rollout" in k["kernel"])
-                _PMC[key] = (k["traffic_bytes_per_launch"], fname)
+                c = classify_kernel(k["kernel"], k.get("humans", 5))
+                if c is None or c[2] is None:
+                    continue
+                key = (c[0], c[2], c[1], k["envs"], int(k.get("steps_per_launch", 1)))
+                _PMC[key] = (k["traffic_bytes_per_launch"], fname, k["kernel"])
     spl = int(round(steps_per_launch))
-    hit = _PMC.get((E, bool(given), spl, spl > 1))
+    fam, mode = expected_kernel(E, N, given, spl), ("given" if given else "orca")
+    hit = _PMC.get((fam, mode, N, E, spl))
     if hit:
-        return hit[0], "PMC, %s" % hit[1]
+        return hit[0], "PMC, %s" % hit[1], hit[2]
     if spl > 1:
-        pts = sorted((t, v[0], v[1]) for (e, g, t, ro), v in _PMC.items() if e == E and g == bool(given) and ro)
+        pts = sorted((t, v[0], v[1], v[2]) for (f, m, n, e, t), v in _PMC.items() if (f, m, n, e) == (fam, mode, N, E))
         if len(pts) >= 2:
             pts.sort(key=lambda x: abs(np.log(x[0] / spl)))
-            (t0, b0, f0), (t1, b1, _) = pts[0], pts[1]
+            (t0, b0, f0, kn), (t1, b1, _, _) = pts[0], pts[1]
             by = b0 + (b1 - b0) * (spl - t0) / (t1 - t0)
-            return int(max(by, 0)), "affine in steps per launch through the PMC runs at %d and %d steps (%s)" % (t0, t1, f0)
-    return None, None
+            return int(max(by, 0)), "affine in steps per launch through the PMC runs at %d and %d steps (%s)" % (t0, t1, f0), kn
+    return None, None, None
 
 
-# 256 CUs x 4 SIMDs, one wave64 vector instruction per 4 cycles at 2.4 GHz.  Four, not two: measured on this chip --
-# SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.03 quad-cycles per instruction in the fused ORCA kernel
-# (profiles/r02_pmc_sq.json), +4 cycles per v_max_i32 beside MFMAs (profiles/r02_mfma_issue.txt), and
-# MI355X_MICROARCH.md's issue-cost table (v_add_f32 / v_fma_f32: 4).  Only packed forms (v_pk_*_f32) retire two
-# float32 operations per lane in those 4 cycles, which is how the chip's 157 TFLOP/s vector peak is defined.
-VALU_PEAK_WAVE_INST_PER_S = 1024 * 2.4e9 / 4
+# 256 CUs x 4 SIMDs x 2.4 GHz / (cycles one wave64 vector instruction occupies a SIMD's vector pipe).  The cycle count
+# is MEASURED (tools/microbench/valu_issue.hip -> profiles/rNN_valu_issue.txt: independent v_fma_f32 / v_cndmask_b32 /
+# v_add_f32 chains with 1, 2 and 4 wavefronts per SIMD); valu_cycles_per_instruction() reads it back.
+VALU_CYCLES_DEFAULT = 4.0
+_VALU_CYC = None
+
+
+def valu_cycles_per_instruction():
+    """(cycles a float32 wave64 vector instruction holds a SIMD, source): the per-SIMD figure of the v_fma_f32 rows
+    of the latest profiles/rNN_valu_issue.txt with the most wavefronts per SIMD -- the rate that more wavefronts
+    cannot improve on --, else the default 4 (MI355X_MICROARCH.md issue-cost table)."""
+    global _VALU_CYC
+    if _VALU_CYC is None:
+        import glob
+        import re
+        _VALU_CYC = (VALU_CYCLES_DEFAULT, "default: MI355X_MICROARCH.md issue-cost table (no profiles/rNN_valu_issue.txt)")
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_valu_issue.txt")))
+        if files:
+            best = None
+            for ln in open(files[-1]):
+                m = re.match(r"v_fma_f32 \(VOP3.*?(\d+) wave\(s\)/SIMD:.*?=\s*([0-9.]+) per instruction on the SIMD", ln)
+                if m and (best is None or int(m.group(1)) > best[0]):
+                    best = (int(m.group(1)), float(m.group(2)))
+            if best:
+                _VALU_CYC = (best[1], "%s: v_fma_f32, %d wavefronts per SIMD" % (os.path.basename(files[-1]), best[0]))
+    return _VALU_CYC
+
+
+def valu_peak_wave_inst_per_s():
+    return 1024 * 2.4e9 / valu_cycles_per_instruction()[0]
+
+
 _SQ = None
 
 
 def valu_roofline(E, N, avg_ms, steps_per_launch, rollout, given=False):
     """Instruction-issue roofline of a kernel that HBM does not bound: VALU wave-instructions per env-step from the
-    committed SQ_INSTS_VALU pass (profiles/rNN_pmc_sq.json) x env-steps per launch / the launch duration measured
-    live, against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 vector instruction (float64 and transcendental
-    instructions occupy the pipe for 8, so a kernel heavy in those saturates below 1.0)."""
+    committed SQ_INSTS_VALU pass (profiles/rNN_pmc_sq.json, latest round, same kernel family / mode / humans / envs
+    as the dispatcher runs for this launch) x env-steps per launch / the launch duration measured live, against
+    1024 SIMDs x 2.4 GHz / the measured cycles per wave64 vector instruction (float64 and transcendental
+    instructions occupy the pipe longer, so a kernel heavy in those saturates below 1.0)."""
     global _SQ
     if _SQ is None:
         _SQ = {}
-        for fname, d in _profiles("r*_pmc_sq*.json"):
+        for fname, d in _profiles("pmc_sq*.json"):
             for k in d.get("kernels", []):
-                _SQ[(k["kind"], k["envs"], k["humans"])] = (k, fname)
-    kind = "rollout" if rollout else ("pairwise" if given else "fused")
-    hit = _SQ.get((kind, E, N)) or (_SQ.get(("quad", E, N)) if kind == "fused" else None)
+                c = classify_kernel(k["kernel"], k.get("humans", 5))
+                if c is not None and c[2] is not None:
+                    _SQ[(c[0], c[2], c[1], k["envs"])] = (k, fname)
+    fam = expected_kernel(E, N, given, 2 if rollout else 1)
+    hit = _SQ.get((fam, "given" if given else "orca", N, E))
     if hit is None:
         return None
     k, fname = hit
     per_env_step = k["valu_per_env_step"]
     ach = per_env_step * E * steps_per_launch / (avg_ms * 1e-3)
-    return {"bound": "valu-issue", "kernel": k["kernel"], "achieved": round(ach / 1e9, 2), "peak": round(VALU_PEAK_WAVE_INST_PER_S / 1e9, 1),
-            "unit": "G wave-instructions/s", "frac": round(ach / VALU_PEAK_WAVE_INST_PER_S, 4),
+    peak = valu_peak_wave_inst_per_s()
+    return {"bound": "valu-issue", "kernel": k["kernel"], "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 1),
+            "unit": "G wave-instructions/s", "frac": round(ach / peak, 4),
+            "peak_cycles_per_instruction": valu_cycles_per_instruction()[0],
+            "peak_source": valu_cycles_per_instruction()[1],
             "valu_wave_instructions_per_env_step": round(per_env_step, 2),
             "all_wave_instructions_per_env_step": round(k.get("insts_per_env_step", 0.0), 2),
             "issue_cycles_per_valu_instruction": (round(4.0 * k["counters_per_launch"]["SQ_ACTIVE_INST_VALU"] /
@@ -218,17 +301,31 @@ def roofline_entry(E, N, avg_ms, extra=None, given=False, steps_per_launch=1):
     ach = by / (avg_ms * 1e-3) / 1e9
     d = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(ach / HBM_PEAK_GBS, 5),
-         "traffic": None, "traffic_source": None,
-         "kernel": ("mcn::env_pair_kernel" if given and N in (5, 10) and E > 4096 * (64 // N) else "mcn::env_step_kernel")
-         if steps_per_launch == 1 else "mcn::env_rollout_quad_kernel",
+         "traffic": None, "traffic_source": None, "traffic_kernel": None,
+         "kernel": "mcn::" + expected_kernel(E, N, given, int(round(steps_per_launch))),
          "envs_per_launch": E, "env_steps_per_launch": int(round(E * steps_per_launch)),
          "algorithmic_bytes_per_launch": int(round(by)),
          "avg_launch_us": round(avg_ms * 1e3, 3)}
-    if N == 5:
-        d["traffic"], d["traffic_source"] = pmc_traffic(E, given, steps_per_launch)
+    d["traffic"], d["traffic_source"], d["traffic_kernel"] = pmc_traffic(E, given, steps_per_launch, N)
     if extra:
         d.update(extra)
     return d
+
+
+_NETS = None
+
+
+def net_traffic(family, E, N):
+    """HBM bytes per launch of a network kernel (sarl_value_kernel, sgan_*_kernel) from profiles/rNN_pmc_nets.json of
+    the latest round: (bytes, source) or (None, None)."""
+    global _NETS
+    if _NETS is None:
+        _NETS = {}
+        for fname, d in _profiles("pmc_nets.json"):
+            for k in d.get("kernels", []):
+                _NETS[(k["family"], k["envs"], k["humans"])] = (k["traffic_bytes_per_launch"], fname)
+    hit = _NETS.get((family, E, N))
+    return (hit[0], "PMC, %s" % hit[1]) if hit else (None, None)
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 MFMA (= fp32 vector peak)
@@ -275,10 +372,7 @@ def extra_configs(device):
     flop = 81 * (N * 124100 + 67000) * E
     out.append({"config": "4096 envs x 5 humans, SARL attention value-net robot (81-action look-ahead), ORCA humans",
                 "ms_per_step": round(ms_step, 4), "env_steps_per_sec": round(E / ms_step * 1e3, 1),
-                "roofline": {"bound": "mfma", "kernel": "mcn::sarl_value_kernel", "achieved": round(flop / ms_net / 1e9, 2),
-                             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop / ms_net / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
-                             "traffic": None, "algorithmic_flop_per_launch": flop, "avg_launch_us": round(ms_net * 1e3, 1),
-                             "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}})
+                "roofline": _sarl_roofline(E, N, ms_net)})
     del env
     # ---- config 4: 4096 envs x 10 humans, model-based rollout with the SGAN predictor ----
     gold = os.path.join(ROOT, "tests", "golden", "g6_sgan.npz")
@@ -331,20 +425,37 @@ def extra_configs(device):
     out.append({"config": "4096 envs x 10 humans per GPU (the shard of BASELINE's 32 768 x 10 on 8 GPUs), ORCA humans, "
                           "random robot actions, one mcn_env_step launch per step",
                 "ms_per_step": round(ms10, 5), "env_steps_per_sec": round(E / ms10 * 1e3, 1),
-                "roofline": roofline_entry(E, N, ms10)})
+                "roofline": roofline_entry(E, N, ms10),
+                "roofline_valu": valu_roofline(E, N, ms10, 1, rollout=False)})
     return out
 
 
+def _sarl_roofline(E, N, ms_net):
+    flop = 81 * (N * 124100 + 67000) * E
+    tr, src = net_traffic("sarl_value_kernel", E, N)
+    return {"bound": "mfma", "kernel": "mcn::sarl_value_kernel", "achieved": round(flop / ms_net / 1e9, 2),
+            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop / ms_net / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
+            "traffic": tr, "traffic_source": src, "algorithmic_flop_per_launch": flop,
+            "avg_launch_us": round(ms_net * 1e3, 1), "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}
+
+
 def _sgan_roofline(E, N, ms):
-    algorithmic = 0.69e6 * E * N
+    """`achieved` / `frac` count the FLOP the kernels EXECUTE (MFMAs issued x 2 048); the reference-formulation count
+    (~0.69 MFLOP per pedestrian at N = 10, more than the kernels need after the pool-net layer split and
+    the folded embeddings) is reported beside it under reference_flop_* and is not a roofline fraction."""
+    reference = 0.69e6 * E * N
     tiles = (E * N + 15) // 16
     executed = tiles * (576 + ((N + 4) // 5) * 1064 + 160) * 2048
+    parts = [net_traffic(f, E, N) for f in ("sgan_encode_kernel", "sgan_pool_kernel", "sgan_decode_kernel")]
+    traffic = sum(p[0] for p in parts) if all(p[0] is not None for p in parts) else None
     return {"bound": "mfma", "kernel": "mcn::sgan_encode_kernel + mcn::sgan_pool_kernel + mcn::sgan_decode_kernel",
-            "achieved": round(algorithmic / ms / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(algorithmic / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-            "algorithmic_flop_per_launch": int(algorithmic), "executed_flop_per_launch": int(executed),
-            "executed_achieved": round(executed / ms / 1e9, 2),
-            "executed_frac": round(executed / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
+            "achieved": round(executed / ms / 1e9, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(executed / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
+            "traffic": traffic, "traffic_source": parts[0][1] if traffic is not None else None,
+            "executed_flop_per_launch": int(executed),
+            "reference_flop_per_launch": int(reference),
+            "reference_flop_rate": round(reference / ms / 1e9, 2),
+            "reference_flop_rate_over_peak": round(reference / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
             "avg_launch_us": round(ms * 1e3, 1), "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}
 
 
@@ -464,9 +575,13 @@ def main():
             run_timed_steps()
 
     gathered = None
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -476,7 +591,7 @@ def main():
         dist.all_gather_into_tensor(gathered, torch.zeros(E, 3, dtype=torch.float32, device=cdev))
 
     def barrier():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -488,7 +603,7 @@ def main():
     else:
         run_timed_steps()
     ev_e.record()
-    if world > 1:
+    if collective:
         # the path's one exchange: episode returns + outcome codes + counts, one fused buffer, one collective
         rb = env.rollout_buffers
         packed = torch.stack([rb["fin_return"][0], rb["fin_info"][0].double(), rb["fin_count"].double()], 1).float()
@@ -496,7 +611,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     env_steps_total = float(E * K * R)
-    if world > 1:
+    if collective:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -536,6 +651,7 @@ def main():
                    "parallelism": "env-shard x%d, no per-step collective" % world},
         "episodes_finished": episodes, "mean_discounted_return": round(mean_ret, 6),
         "gathered_episode_records": None if gathered is None else int((gathered[:, 2] > 0).sum().item()),
+        "collective": (dist.get_backend() if collective else None),
         "roofline": roof,
         "roofline_valu": valu,
     }
@@ -578,7 +694,7 @@ def main():
             sweep.append(roofline_entry(Es, N, n_ms, {"mode": "pairwise + reward + integrate, no Explorer record / "
                                                               "auto-restart (plain ModelCrowdSim.step)",
                                                        "env_steps_per_sec": round(Es / (n_ms * 1e-3), 1)}, given=True))
-            sweep[-1]["traffic"] = None
+            sweep[-1]["traffic"] = sweep[-1]["traffic_source"] = sweep[-1]["traffic_kernel"] = None   # PMC runs carry the record
             del gv
             del env_s, a_s
         result["roofline_sweep"] = sweep
@@ -594,7 +710,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

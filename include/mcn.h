@@ -318,12 +318,13 @@ typedef struct mcn_tuning {
     int32_t quad_split;      /* quad kernel: ORCA and float64 pairwise work on two cooperating wavefronts (0/1) */
     int32_t rollout_fused;   /* mcn_env_rollout: one T-step launch (1) or T single-step launches (0) */
     int32_t rollout_split;   /* fused rollout: two cooperating wavefronts per env group (0/1) */
-    int32_t reserved;        /* -1 */
+    int32_t step_block;      /* lane-per-human step kernels: workgroup of 64 or 256 lanes (-1: 64 up to 4096 wavefronts, 256 above) */
     int32_t diag_noop;       /* DIAGNOSTIC build only (make stamp): env kernels return at entry; MCN_EINVAL otherwise */
     int32_t pair_stream;     /* given-velocity step: streaming kernel (env_pair.hip) 1 wherever it applies / 0 never */
 } mcn_tuning;
 
-/* NULL restores the initial values.  Returns MCN_EINVAL for out-of-range fields. */
+/* NULL restores the initial values.  Returns MCN_EINVAL for out-of-range fields.  The settings are one unsynchronised
+ * process-wide struct read at every launch: do not call mcn_set_tuning while another thread is launching. */
 int mcn_set_tuning(const mcn_tuning *t);
 int mcn_get_tuning(mcn_tuning *t);
 

@@ -92,7 +92,7 @@ RULE_CIRCLE, RULE_SQUARE = 0, 1
 class Tuning(C.Structure):
     """mcn_tuning: dispatch overrides, -1 = automatic."""
     _fields_ = [(k, _i) for k in ("force_generic", "quad_max_envs", "quad_split", "rollout_fused", "rollout_split",
-                                  "reserved", "diag_noop", "pair_stream")]
+                                  "step_block", "diag_noop", "pair_stream")]
 
 
 class McnError(RuntimeError):
@@ -158,13 +158,13 @@ def get_tuning():
 
 def set_tuning(**kw):
     """Override kernel dispatch (tests, tuning): set_tuning(quad_max_envs=0, force_generic=1); no arguments =
-    back to the initial (automatic / environment) values.  Returns the previous settings."""
+    back to the initial (automatic / environment) values.  The given fields are laid over the CURRENT settings.
+    Returns the previous settings.  Process-wide and unsynchronised: not while another thread launches."""
     prev = get_tuning()
     if not kw:
         check(lib.mcn_set_tuning(None), "mcn_set_tuning")
         return prev
-    t = Tuning(force_generic=0, quad_max_envs=-1, quad_split=-1, rollout_fused=-1, rollout_split=-1,
-               reserved=-1, diag_noop=0, pair_stream=-1)
+    t = Tuning.from_buffer_copy(prev)            # overlay: a nested tuned(...) keeps the outer overrides
     for k, v in kw.items():
         if k not in dict(Tuning._fields_):
             raise TypeError("unknown tuning field %r" % k)

@@ -470,7 +470,8 @@ int launch_env_step(const StepParams &p, hipStream_t stream)
     if ((p.pair_stream > 0 || (p.pair_stream < 0 && waves_total > 4096)) && launch_env_pair(p, stream))
         return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
     // small batches: one wavefront per workgroup so the grid covers as many CUs as possible
-    if (waves_total <= 4096) dispatch<64>(p, waves_total, stream);
+    const bool one_wave = p.step_block > 0 ? p.step_block == 64 : waves_total <= 4096;
+    if (one_wave) dispatch<64>(p, waves_total, stream);
     else                     dispatch<256>(p, (waves_total + 3) / 4, stream);
     return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
 }

@@ -52,7 +52,7 @@ static mcn_tuning tuning_from_env()
     t.quad_split = env_or("MCN_QUAD_SPLIT", -1);
     t.rollout_fused = env_or("MCN_ROLLOUT_FUSED", -1);
     t.rollout_split = env_or("MCN_ROLLOUT_SPLIT", -1);
-    t.reserved = -1;
+    t.step_block = env_or("MCN_STEP_BLOCK", -1);
     t.pair_stream = env_or("MCN_PAIR_STREAM", -1);
     return t;
 }
@@ -101,6 +101,7 @@ static int fill_step_params(mcn::StepParams &p, const mcn_env_cfg *cfg, const mc
     const mcn_tuning &tu = tuning();
     p.force_generic = tu.force_generic > 0 ? 1 : 0;
     p.pair_stream = tu.pair_stream;
+    p.step_block = tu.step_block;
 #ifdef MCN_DIAG
     p.debug_noop = tu.diag_noop;
 #endif
@@ -123,6 +124,8 @@ int mcn_set_tuning(const mcn_tuning *t)
 {
     if (!t) { g_tuning = tuning_from_env(); g_tuning_init = true; return MCN_OK; }
     if (t->quad_split > 1 || t->rollout_fused > 1 || t->rollout_split > 1 || t->pair_stream > 1 || t->force_generic < 0 || t->force_generic > 1) return MCN_EINVAL;
+    if (t->quad_max_envs < -1 || t->quad_split < -1 || t->rollout_fused < -1 || t->rollout_split < -1 || t->pair_stream < -1) return MCN_EINVAL;
+    if (t->step_block != -1 && t->step_block != 64 && t->step_block != 256) return MCN_EINVAL;
 #ifndef MCN_DIAG
     if (t->diag_noop) return MCN_EINVAL;          // kernels that do nothing exist in the diagnostic build only
 #endif

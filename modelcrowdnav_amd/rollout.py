@@ -131,7 +131,9 @@ class VecExplorer(object):
         rank, ws = mdist.world()
         E_local = env.num_envs
         E_total = total_envs if total_envs is not None else E_local * ws
-        lo = rank * E_local
+        lo, hi = mdist.shard(E_total, rank, ws)                # shards may differ by one env (E_total % ws != 0)
+        if hi - lo != E_local:
+            raise ValueError("rank %d of %d holds %d envs; its shard of %d is [%d, %d)" % (rank, ws, E_local, E_total, lo, hi))
         if hasattr(self.policy, "set_phase"):
             self.policy.set_phase(phase)
         n, rule = env._phase_rule(phase)
@@ -244,7 +246,8 @@ class VecExplorer(object):
         dng = torch.zeros(2, E_local, rounds, dtype=torch.float64, device=bufs["fin_return"].device)
         dng[0, :, 0], dng[1, :, 0] = bufs["danger_count"].double(), bufs["danger_dist_sum"]
         rec = mdist.gather_records(bufs["fin_return"][:rounds].t().contiguous(), bufs["fin_info"][:rounds].t().contiguous(),
-                                   bufs["fin_time"][:rounds].t().contiguous(), extras=(dng[0], dng[1]))
+                                   bufs["fin_time"][:rounds].t().contiguous(), extras=(dng[0], dng[1]),
+                                   equal_shards=(E_total % ws == 0))
         ret = rec["return"].view(-1, rounds).cpu().numpy()        # [E_total, rounds]
         inf = rec["info"].view(-1, rounds).cpu().numpy()
         tim = rec["time"].view(-1, rounds).cpu().numpy()

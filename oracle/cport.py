@@ -67,6 +67,13 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def lp3_entries(reset=True):
+    """Agents that fell through to linearProgram3 since the last reset (coverage assertions)."""
+    f = lib().mcn_oracle_lp3_entries
+    f.restype = C.c_long
+    return int(f(C.c_int(1 if reset else 0)))
+
+
 def point_to_segment_dist(x1, y1, x2, y2, x3, y3):
     return lib().mcn_oracle_point_to_segment_dist(x1, y1, x2, y2, x3, y3)
 

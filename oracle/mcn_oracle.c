@@ -116,10 +116,16 @@ static int lp2(const hline *L, int n, float radius, v2 opt, int dir_opt, v2 *res
     return n;
 }
 
+/* Test hook: how many agents fell through to the 3-D LP since the last reset (coverage assertions in tests/;
+   not thread-safe, the oracle is single-threaded). */
+static long g_lp3_entries = 0;
+long mcn_oracle_lp3_entries(int reset) { const long n = g_lp3_entries; if (reset) g_lp3_entries = 0; return n; }
+
 /* Minimise the maximum penetration once lp2 failed at line `begin`. */
 static void lp3(const hline *L, int n, int begin, float radius, v2 *res)
 {
     float dist = 0.0f;
+    ++g_lp3_entries;
     hline P[MCN_MAX_NEIGH];
     for (int i = begin; i < n; ++i) {
         if (vdet(L[i].d, vsub(L[i].p, *res)) > dist) {
@@ -390,10 +396,12 @@ void mcn_oracle_env_step(const mcn_oracle_cfg *c, int E, int N, int update,
             for (int i = 0; i < N; ++i)
                 for (int j = i + 1; j < N; ++j) {
                     const double dx = hpx[b + i] - hpx[b + j], dy = hpy[b + i] - hpy[b + j];
-                    /* reference: (dx**2 + dy**2)**(1/2), i.e. libm pow(x, 0.5).  sqrt() is used here and in the kernels: it is
-                       the correctly rounded value; glibc's pow differs from it by one ulp for ~0.05 % of arguments, which never
-                       changes the sign of `d` (tests/test_oracle_golden.py::test_pow_half_vs_sqrt_never_flips_the_overlap_test) */
-                    const double d = sqrt(dx * dx + dy * dy) - hr[b + i] - hr[b + j];
+                    /* reference: (dx**2 + dy**2)**(1/2), i.e. CPython float pow = libm pow(x, 0.5), kept literally: the
+                       oracle follows the reference, not the kernels.  The kernels use the correctly rounded sqrt (a documented
+                       deviation): glibc's pow differs from it by one ulp for ~0.05 % of arguments, which can change
+                       the sign of `d` only for pairs within one ulp of touching
+                       (tests/test_oracle_golden.py::test_pow_half_vs_sqrt_never_flips_the_overlap_test) */
+                    const double d = pow(dx * dx + dy * dy, 0.5) - hr[b + i] - hr[b + j];
                     if (d < 0) ++hh;
                 }
         }

@@ -1,9 +1,18 @@
 """CPU: bench.py's roofline bookkeeping against the committed PMC summaries (profiles/rNN_pmc_*.json) -- the fields
-the driver's JSON line must carry (`roofline.traffic` for whatever launch length ran, `roofline_valu`)."""
+the driver's JSON line must carry (`roofline.traffic` for whatever launch length ran, `roofline_valu`), and the rule
+that a traffic figure is only ever attached to the kernel it was measured on, from the latest round's files."""
+import glob
 import json
 import os
+import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _latest(pattern):
+    files = glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + pattern))
+    last = max(re.match(r"r(\d\d)_", os.path.basename(f)).group(1) for f in files)
+    return [f for f in files if os.path.basename(f).startswith("r%s_" % last)], "r%s" % last
 
 
 def test_algorithmic_bytes_follow_survey_8d():
@@ -12,22 +21,67 @@ def test_algorithmic_bytes_follow_survey_8d():
     assert bench.pairwise_bytes_per_env_step(5) == 566
 
 
+def test_kernel_classification_reads_template_arguments():
+    import bench
+    c = bench.classify_kernel
+    assert c("mcn::env_pair_kernel<5>") == ("env_pair_kernel", 5, "given", 1)
+    assert c("mcn::env_pair_kernel<10>") == ("env_pair_kernel", 10, "given", 1)
+    assert c("mcn::env_step_kernel<256, 5, 0, 0, 2>") == ("env_step_kernel", 5, "orca", 1)       # HH = 2 is not MODE
+    assert c("mcn::env_step_kernel<64, 0, 0, 2, 0>", 5) == ("env_step_kernel", 5, "given", 1)
+    assert c("mcn::env_step_kernel<64, 10, 0, 0, 2>") == ("env_step_kernel", 10, "orca", 1)
+    assert c("mcn::env_step_quad_kernel<5, 0, false>") == ("env_step_quad_kernel", 5, "orca", 4)
+    assert c("mcn::env_rollout_quad_kernel<5, 0, false, true>") == ("env_rollout_quad_kernel", 5, "orca", 8)
+    assert c("mcn::sarl_value_kernel", 5)[0] == "sarl_value_kernel"
+    # the dispatcher's choices (csrc/mcn_api.hip, env_step.hip)
+    e = bench.expected_kernel
+    assert e(4096, 5, False) == "env_step_quad_kernel" and e(1 << 20, 5, False) == "env_step_kernel"
+    assert e(4096, 5, True) == "env_step_kernel" and e(1 << 20, 5, True) == "env_pair_kernel"
+    assert e(4096, 10, False) == "env_step_kernel" and e(4096, 5, False, 20) == "env_rollout_quad_kernel"
+
+
 def test_traffic_lookup_exact_and_affine_in_launch_length():
     import bench
-    roll = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_env_rollout.json")))["kernels"]
+    files, tag = _latest("pmc_env_rollout.json")
+    roll = json.load(open(files[0]))["kernels"]
     by_t = {k["steps_per_launch"]: k["traffic_bytes_per_launch"] for k in roll}
     assert set(by_t) >= {20, 100, 1000}
-    t20, src = bench.pmc_traffic(4096, False, 20)
-    assert t20 == by_t[20] and "r02_pmc_env_rollout" in src
-    t50, src50 = bench.pmc_traffic(4096, False, 50)            # between two measured launch lengths
+    t20, src, kn = bench.pmc_traffic(4096, False, 20)
+    assert t20 == by_t[20] and tag + "_pmc_env_rollout" in src and "env_rollout_quad_kernel" in kn
+    t50, src50, _ = bench.pmc_traffic(4096, False, 50)            # between two measured launch lengths
     assert by_t[20] < t50 < by_t[100] and "affine" in src50
     want = by_t[20] + (by_t[100] - by_t[20]) * (50 - 20) / 80
     assert abs(t50 - want) <= 1
-    t1, src1 = bench.pmc_traffic(4096, False, 1)               # one mcn_env_step launch per step (quad kernel)
-    assert t1 and "pmc_env_step" in src1
-    assert bench.pmc_traffic(12345, False, 1) == (None, None)   # no such run: null, not a guess
+    t1, src1, kn1 = bench.pmc_traffic(4096, False, 1)             # one mcn_env_step launch per step (quad kernel)
+    assert t1 and "pmc_env_step" in src1 and "env_step_quad_kernel" in kn1
+    assert bench.pmc_traffic(12345, False, 1) == (None, None, None)   # no such run: null, not a guess
     # real traffic of a fused launch is a fraction of the algorithmic bytes (state stays in registers)
     assert t20 < 0.5 * bench.algorithmic_bytes_per_env_step(5) * 4096 * 20
+
+
+def test_traffic_is_only_attached_to_the_kernel_it_was_measured_on():
+    """the pair kernel's counters once landed on the fused-ORCA rows.  Every row's traffic must
+    come from a same-round file entry whose kernel family, mode, humans and envs are the row's own."""
+    import bench
+    files, tag = _latest("pmc_env_*.json")
+    entries = [k for f in files for k in json.load(open(f))["kernels"]]
+    for E, N, given, spl in [(4096, 5, False, 1), (1 << 20, 5, False, 1), (1 << 20, 5, True, 1), (4096, 5, True, 1),
+                             (4096, 5, False, 20), (4096, 10, False, 1), (1 << 18, 10, False, 1), (1 << 16, 5, False, 1)]:
+        row = bench.roofline_entry(E, N, 0.1, given=given, steps_per_launch=spl)
+        if row["traffic"] is None:
+            assert row["traffic_source"] is None and row["traffic_kernel"] is None
+            continue
+        assert tag + "_" in row["traffic_source"], row["traffic_source"]
+        fam, n, mode, _ = bench.classify_kernel(row["traffic_kernel"], N)
+        assert "mcn::" + fam == row["kernel"] and n == N and mode == ("given" if given else "orca")
+        if "affine" not in row["traffic_source"]:
+            src = [k for k in entries if k["kernel"] == row["traffic_kernel"] and k["envs"] == E
+                   and int(k.get("steps_per_launch", 1)) == spl]
+            assert src and src[0]["traffic_bytes_per_launch"] == row["traffic"]
+    # the two 2^20 rows are different kernels with different traffic
+    a = bench.roofline_entry(1 << 20, 5, 0.2)
+    b = bench.roofline_entry(1 << 20, 5, 0.13, given=True)
+    if a["traffic"] and b["traffic"]:
+        assert a["traffic_kernel"] != b["traffic_kernel"] and a["traffic"] != b["traffic"]
 
 
 def test_roofline_entries_carry_traffic_and_valu():
@@ -36,9 +90,13 @@ def test_roofline_entries_carry_traffic_and_valu():
     assert e["traffic"] and e["kernel"] == "mcn::env_rollout_quad_kernel" and e["bound"] == "hbm"
     assert abs(e["achieved"] - 622 * 4096 * 20 / 74.5e-6 / 1e9) < 1.0 and e["frac"] == round(e["achieved"] / 8000.0, 5)
     v = bench.valu_roofline(4096, 5, 0.0745, 20, rollout=True)
-    assert v["bound"] == "valu-issue" and 0.05 < v["frac"] < 1.0 and v["peak"] == 614.4
-    sq = {k["kind"]: k for k in json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq.json")))["kernels"]}
-    assert abs(v["valu_wave_instructions_per_env_step"] - sq["rollout"]["valu_per_env_step"]) < 0.01
+    cyc, src = bench.valu_cycles_per_instruction()
+    assert v["bound"] == "valu-issue" and 0.02 < v["frac"] < 1.0 and abs(v["peak"] - 1024 * 2.4 / cyc) < 0.1
+    assert v["peak_cycles_per_instruction"] == cyc and 1.9 <= cyc <= 4.1
+    files, _ = _latest("pmc_sq.json")
+    sq = {(bench.classify_kernel(k["kernel"], k["humans"])[0], k["envs"], k["humans"]): k
+          for k in json.load(open(files[0]))["kernels"]}
+    assert abs(v["valu_wave_instructions_per_env_step"] - sq[("env_rollout_quad_kernel", 4096, 5)]["valu_per_env_step"]) < 0.01
     f = bench.valu_roofline(1 << 20, 5, 0.2, 1, rollout=False)
     p = bench.valu_roofline(1 << 20, 5, 0.13, 1, rollout=False, given=True)
     assert f["kernel"].startswith("mcn::env_step_kernel") and p["kernel"].startswith("mcn::env_pair_kernel")

@@ -4,6 +4,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -22,7 +23,7 @@ def _worker(rank, ws, port, E_total, rounds, out_dir):
     ret = torch.stack([gid * 10 + k for k in range(rounds)], 1)
     info = torch.stack([((gid.long() + k) % 3 + 2).to(torch.uint8) for k in range(rounds)], 1)
     tim = ret / 4
-    rec = mdist.gather_records(ret, info, tim)
+    rec = mdist.gather_records(ret, info, tim, equal_shards=(E_total % ws == 0))
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), ret=rec["return"].numpy(), info=rec["info"].numpy(),
              time=rec["time"].numpy())
     import torch.distributed as dist
@@ -40,9 +41,10 @@ def test_shard_covers_everything():
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
 
 
-def test_gather_records_world2(tmp_path):
-    E_total, rounds, ws = 64, 3, 2
-    port = 29500 + (os.getpid() % 2000)
+@pytest.mark.parametrize("E_total", [64, 33])          # 33 on two ranks: shards of 17 and 16 records x rounds
+def test_gather_records_world2(tmp_path, E_total):
+    rounds, ws = 3, 2
+    port = 29500 + (os.getpid() % 2000) + E_total % 7
     mp.spawn(_worker, args=(ws, port, E_total, rounds, str(tmp_path)), nprocs=ws, join=True)
     outs = [np.load(os.path.join(str(tmp_path), "r%d.npz" % r)) for r in range(ws)]
     g = np.arange(E_total, dtype=np.float64)

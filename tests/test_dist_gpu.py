@@ -12,18 +12,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_vec_explorer_equals_single_process(tmp_path):
+@pytest.mark.parametrize("E_total", [32, 33])          # 33: unequal shards (17 + 16 envs), sizes exchanged
+def test_two_rank_vec_explorer_equals_single_process(tmp_path, E_total):
     from modelcrowdnav_amd.rollout import VecExplorer
     from tests import helpers as H
     from tests.test_rollout_gpu import _goal_seeking
-    E_total, N, k = 32, 5, 80
+    N, k = 5, 80
     env = H.make_vec_env(E_total, N)
     env.track_human_times = False
     env.export_human_actions = False
     ex = VecExplorer(env, env.robot, gamma=0.9, policy=object())
     want = list(ex.run_k_episodes(k, "test", action_fn=_goal_seeking, returnNav=True))
     want_rec = ex.last_records
-    port = 30100 + (os.getpid() % 2000)
+    port = 30100 + (os.getpid() % 2000) + E_total % 7
     outs = [str(tmp_path / ("r%d.json" % r)) for r in range(2)]
     envv = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, "-m", "tests.dist_worker", str(r), "2", str(port), str(E_total), str(N),
@@ -45,3 +46,53 @@ def test_two_rank_vec_explorer_equals_single_process(tmp_path):
         for key in ("returns", "infos", "times"):
             assert got["records"][key] == want_rec[key], key
     assert len(set(want_rec["infos"])) > 1
+
+
+def _run_child(args, timeout=420, env_extra=None):
+    envv = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
+    pr = subprocess.Popen(args, cwd=ROOT, env=envv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        out, err = pr.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        pr.kill()
+        raise
+    assert pr.returncode == 0, out[-3000:] + "\n" + err[-3000:]
+    return out
+
+
+def test_rccl_world_size_one_gather_on_device_tensors(tmp_path):
+    """RCCL itself: ONE fresh child process forms a world-size-1 `nccl` (= RCCL) group on the GPU and runs
+    dist.gather_records on device tensors (the all_gather_into_tensor of the rollout path, incl. the size exchange
+    of unequal shards) and a sharded VecExplorer rollout whose records come back through that collective."""
+    out = str(tmp_path / "rccl.json")
+    port = 31100 + (os.getpid() % 2000)
+    _run_child([sys.executable, "-m", "tests.rccl_worker", str(port), out])
+    got = json.load(open(out))
+    assert got["backend"] == "nccl" and got["world"] == 1
+    assert got["gather_equal_ok"] and got["gather_sizes_ok"] and got["records_on_cuda"]
+    # the rollout through the RCCL collective equals the same rollout without a process group
+    from modelcrowdnav_amd.rollout import VecExplorer
+    from tests import helpers as H
+    from tests.test_rollout_gpu import _goal_seeking
+    env = H.make_vec_env(32, 5)
+    env.track_human_times = False
+    env.export_human_actions = False
+    ex = VecExplorer(env, env.robot, gamma=0.9, policy=object())
+    want = list(ex.run_k_episodes(80, "test", action_fn=_goal_seeking, returnNav=True))
+    assert got["result"] == want
+    for key in ("returns", "infos", "times"):
+        assert got["records"][key] == ex.last_records[key], key
+
+
+def test_bench_collective_branches_on_rccl():
+    """bench.py's N > 1 branches (graph captured before init_process_group, communicator warm-up, the one
+    all_gather_into_tensor of episode records, MAX / SUM all-reduces, barrier) executed on RCCL with one rank."""
+    port = 33100 + (os.getpid() % 2000)
+    out = _run_child([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "2", "--force-collective",
+                      "--no-sweep", "--no-extra", "--no-cpu-baseline", "--min-timed-ms", "5"],
+                     env_extra={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+                                "MASTER_PORT": str(port)})
+    line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["collective"] == "nccl"
+    assert line["gathered_episode_records"] is not None and line["gathered_episode_records"] >= 0
+    assert line["value"] > 1e6

@@ -46,15 +46,20 @@ def _step_both(env, st, ax, ay, update, policy=cport.HUMANS_ORCA, given=None):
                                                  (7, False, True), (9, True, False), (13, False, True),
                                                  (32, False, False)])
 @pytest.mark.parametrize("update", [True, False])
-@pytest.mark.parametrize("kernel", ["auto", "lane-per-human", "run-time-N", "quad", "quad-split"])
+@pytest.mark.parametrize("kernel", ["auto", "lane-per-human", "lane-per-human-256", "run-time-N", "run-time-N-256", "quad",
+                                    "quad-split"])
 def test_step_matches_oracle_bitexact(N, visible, randomize, update, kernel, tuning):
     # the same arithmetic exists in several decompositions (env_step.hip with compile-time or run-time N,
     # env_step_quad.hip +- wavefront split); mcn_set_tuning (the `tuning` fixture) pins which one the dispatcher picks
-    if kernel == "lane-per-human":
+    if kernel.startswith("lane-per-human"):
         tuning(quad_max_envs=0)
-    elif kernel == "run-time-N":
+    elif kernel.startswith("run-time-N"):
         tuning(quad_max_envs=0)
         tuning(force_generic=1)
+    if kernel.endswith("-256"):
+        # the 4-wavefront workgroups that batches above 4096 wavefronts get (pair rows parked across wavefronts,
+        # the register-resident 3-D LP `lp3_static` instead of the wavefront-cooperative one): forced at a small size
+        tuning(step_block=256)
     elif kernel.startswith("quad"):
         if N - 1 + int(visible) > 4:
             pytest.skip("quad kernel handles at most 4 neighbours")
@@ -65,7 +70,12 @@ def test_step_matches_oracle_bitexact(N, visible, randomize, update, kernel, tun
     env = H.make_vec_env(E, N, robot_visible=visible)
     st = H.random_state(rng, E, N, randomize=randomize)
     sp, aa = rng.uniform(0, 1, E), rng.uniform(0, 2 * np.pi, E)
+    cport.lp3_entries(reset=True)
     got, ref, ref_st = _step_both(env, st, sp * np.cos(aa), sp * np.sin(aa), update)
+    # the inputs reach the rare paths: humans that fall through to the 3-D LP, overlapping human pairs
+    if N >= 5:
+        assert cport.lp3_entries() > 20
+        assert int(ref["hh_count"].sum()) > 20
     for k in ("done", "info", "hh_count"):
         assert np.array_equal(got[k], ref[k]), k
     for k in [k for k in ref if k not in ("done", "info", "hh_count")]:
@@ -283,7 +293,8 @@ def test_rollout_launch_equals_single_steps(N, visible, with_pool, split, tuning
 def test_rollout_entry_point_with_larger_crowds(N, visible):
     """mcn_env_rollout for crowds the fused launch does not cover (more than 4 ORCA neighbours per human): the entry
     point runs its T single-step launches (the wavefront-cooperative 3-D LP of one-wavefront workgroups included) and
-    must leave every byte as T mcn_env_step calls do; and both equal the oracle's trajectory."""
+    must leave every byte as T mcn_env_step calls do (the oracle comparison of these kernels over whole trajectories
+    is test_larger_crowd_trajectories_match_oracle)."""
     torch = _torch()
     E, T = 300, 110
     rng = np.random.RandomState(N)
@@ -300,6 +311,36 @@ def test_rollout_entry_point_with_larger_crowds(N, visible):
     for k in sa:
         assert np.array_equal(sa[k].view(np.uint8), sb[k].view(np.uint8)), k
     assert int(a.rollout_buffers["fin_count"].min().item()) >= 1
+
+
+@pytest.mark.parametrize("N", [7, 10])
+@pytest.mark.parametrize("block", [64, 256])
+def test_larger_crowd_trajectories_match_oracle(N, block, tuning):
+    """Crowds of 7 / 10 (test_mul_env.py:31-33, BASELINE config 5) over 40 steps of circle crossing against the
+    oracle's trajectory, bit for bit, through both lane-per-human decompositions: one-wavefront workgroups with the
+    wavefront-cooperative 3-D LP (what batches up to 4096 wavefronts get) and 4-wavefront workgroups with the
+    register-resident one (larger batches).  The crossing is dense enough that hundreds of humans per step take the
+    3-D LP."""
+    torch = _torch()
+    E, T = 1024, 40
+    tuning(step_block=block)
+    env = H.make_vec_env(E, N)
+    env.reset("test", test_cases=[i % 500 for i in range(E)])
+    st = H.download(env)
+    cfg = H.oracle_cfg_for(env)
+    rng = np.random.RandomState(N)
+    cport.lp3_entries(reset=True)
+    for t in range(T):
+        sp, aa = rng.uniform(0, 1, E), rng.uniform(0, 2 * np.pi, E)
+        ax, ay = sp * np.cos(aa), sp * np.sin(aa)
+        ob, reward, done, info = env.step(torch.from_numpy(np.stack([ax, ay], -1)).to(env.device))
+        ref = cport.env_step(cfg, st, ax, ay, update=True)
+        assert np.array_equal(done.cpu().numpy(), ref["done"]), t
+        assert np.array_equal(reward.cpu().numpy(), ref["reward"]), t
+        assert np.array_equal(env.hh_count.cpu().numpy(), ref["hh_count"]), t
+        assert np.array_equal(env.human_act.cpu().numpy(), ref["human_act"]), t
+    H.assert_state_equal(H.download(env), st, what="after %d steps" % T)
+    assert cport.lp3_entries() > 100 * T // 10, "the crossing should drive humans into the 3-D LP"
 
 
 @pytest.mark.parametrize("split", ["0", "1"])

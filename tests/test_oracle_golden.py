@@ -99,7 +99,7 @@ def test_action_table_bitexact(golden_dir):
 
 def test_pow_half_vs_sqrt_never_flips_the_overlap_test():
     """crowd_sim.py:371 computes the human-human distance as (dx**2 + dy**2)**(1/2) -- CPython float pow, i.e. libm
-    pow(x, 0.5); the oracle and the kernels use the correctly rounded sqrt.  On this libm the two differ by one ulp
+    pow(x, 0.5), which the oracle keeps; the kernels use the correctly rounded sqrt (documented deviation).  On this libm the two differ by one ulp
     for ~0.05 % of arguments; what the env derives from it is only the sign of `dist - r_i - r_j`, and that sign is the
     same for every argument within 2000 ulps of the touching distance of the shipped radii (exhaustive); for random
     radii it can differ only where |dist - r_i - r_j| is itself below one ulp (a measure-zero boundary; the count is

@@ -94,6 +94,47 @@ def test_predict_batch_matches_oracle(N):
             assert best[e] == idx and tuple(actions[e]) == tuple(table[idx])
 
 
+@pytest.mark.parametrize("N", [5, 10])
+def test_predict_batch_at_benchmark_size_matches_oracle(N):
+    """The grids bench.py times (BASELINE configs 3 / 4: 4096 envs x 81 actions = 20 736 16-pair tiles, ten rounds
+    of the resident workgroups): 64 sampled envs -- first, last, the tile-straddling ones and a random spread --
+    against the torch-fp32 restatement (multi_human_rl.py:35-63, sarl.py:28-65)."""
+    import torch
+    rng = np.random.RandomState(40 + N)
+    E = 4096
+    pol = _policy(seed=3)
+    env = H.make_vec_env(E, N)
+    st = H.random_state(rng, E, N, randomize=True)
+    H.upload(env, st)
+    actions, best, values = pol.predict_batch(env, want_values=True)
+    torch.cuda.synchronize()
+    values, best, actions = values.cpu().numpy(), best.cpu().numpy(), actions.cpu().numpy()
+    assert values.shape == (E, 81) and np.isfinite(values).all()
+    w = {k: v.detach().cpu() for k, v in pol.model.state_dict().items()}
+    table = pol._action_table
+    sample = sorted(set([0, 1, 15, 16, 2047, 2048, E - 2, E - 1] + rng.choice(E, 56, replace=False).tolist()))
+    worst = 0.0
+    for e in sample:
+        row = [st.rpx[e], st.rpy[e], st.rvx[e], st.rvy[e], st.rr[e], st.rgx[e], st.rgy[e], 1.0, 0.0]
+        hum = np.stack([st.hpx[e], st.hpy[e], st.hvx[e], st.hvy[e], st.hr[e]], 1)
+        reached = float(np.linalg.norm((st.rpy[e] - st.rgy[e], st.rpx[e] - st.rgx[e]))) < st.rr[e]
+        if reached:
+            assert best[e] == -1 and tuple(actions[e]) == (0.0, 0.0)
+            continue
+        ref, idx = pyref.sarl_predict(w, row, hum, table)
+        np.testing.assert_allclose(values[e], ref, rtol=0, atol=TOL, err_msg="env %d" % e)
+        worst = max(worst, float(np.abs(values[e] - ref).max()))
+        assert best[e] == int(np.argmax(values[e]))
+        top2 = np.sort(ref)[-2:]
+        if top2[1] - top2[0] > 2 * TOL:
+            assert best[e] == idx and tuple(actions[e]) == tuple(table[idx])
+    # every env's action is the table row of its own argmax (the whole batch, not only the sample)
+    moving = best >= 0
+    assert np.array_equal(best[moving], np.argmax(values[moving], 1))
+    assert np.array_equal(actions[moving], table[best[moving]])
+    print("SARL 4096 x %d: max |value - reference| over %d sampled envs = %.3g" % (N, len(sample), worst))
+
+
 def test_epsilon_greedy_in_train_phase():
     """multi_human_rl.py:27-29 per env: phase 'train' with epsilon = 1 replaces every choice by a uniformly drawn
     table action (except robots already on their goal, which return before the draw), epsilon = 0 is the greedy

@@ -68,8 +68,7 @@ def _load_sd(model, g, prefix):
     model.load_state_dict(sd)
 
 
-@pytest.mark.parametrize("mode", ["batch", "epoch"])
-def test_trainer_steps_match_reference_trainer(mode, golden_dir):
+def check_trainer_against_reference(mode, golden_dir, device, atol):
     """utils/trainer.py against the REAL reference Trainer (crowd_nav/utils/trainer.py:19-82; fixture
     tests/golden/g10_trainer.npz from tests/golden_tools/gen_golden_nets.py:g10_trainer): same seeded ValueNetwork,
     same memory rows, lr 0.01; three optimize_batch(1) calls over a one-batch memory / two optimize_epoch(1) calls over a
@@ -81,22 +80,30 @@ def test_trainer_steps_match_reference_trainer(mode, golden_dir):
     model = _model(seed=3)
     _load_sd(model, g, "w0__")
     states, values = torch.from_numpy(g[mode + "_states"]), torch.from_numpy(g[mode + "_values"])
-    mem = ReplayMemory(states.shape[0])
-    mem.push_batch(states, values.reshape(-1))
-    tr = Trainer(model, mem, torch.device("cpu"), 100)
+    model.to(device)
+    mem = ReplayMemory(states.shape[0], device=device) if device.type != "cpu" else ReplayMemory(states.shape[0])
+    mem.push_batch(states.to(device), values.reshape(-1).to(device))
+    tr = Trainer(model, mem, device, 100)
     tr.set_learning_rate(0.01)
     if mode == "batch":
         losses = [tr.optimize_batch(1) for _ in range(3)]
     else:
         losses = [tr.optimize_epoch(1, perms=g["epoch_perms"][i:i + 1]) for i in range(2)]
-    np.testing.assert_allclose(losses, g[mode + "_losses"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(losses, g[mode + "_losses"], rtol=0, atol=atol)
+    worst = 0.0
     for k, v in model.state_dict().items():
         want = g[mode + "_w1__" + k.replace(".", "__")]
-        np.testing.assert_allclose(v.numpy(), want, rtol=0, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(v.cpu().numpy(), want, rtol=0, atol=atol, err_msg=k)
+        worst = max(worst, float(np.abs(v.cpu().numpy() - want).max()))
+    return worst
 
 
-@pytest.mark.parametrize("mode", ["rl", "il"])
-def test_value_targets_match_reference_update_memory(mode, golden_dir):
+@pytest.mark.parametrize("mode", ["batch", "epoch"])
+def test_trainer_steps_match_reference_trainer(mode, golden_dir):
+    check_trainer_against_reference(mode, golden_dir, torch.device("cpu"), 1e-6)
+
+
+def check_value_targets_against_reference(mode, golden_dir, device, atol):
     """rollout.value_targets (the batched Explorer.update_memory / DataGen.update_memory) against the REAL reference's
     Explorer.update_memory (explorer.py:153-186; fixture tests/golden/g12_update_memory.npz): three episodes of 7 / 12 /
     1 steps laid side by side as three envs, RL targets through a seeded target network, IL discounted tail sums."""
@@ -119,11 +126,19 @@ def test_value_targets_match_reference_update_memory(mode, golden_dir):
         dones[L - 1, e] = True
         infos[L - 1, e] = _hip.INFO_REACHGOAL if e != 1 else _hip.INFO_COLLISION
     gbar = pow(0.9, 0.25 * 1.0)
-    s, v = value_targets(states, rewards, dones, infos, mode == "il", gbar, target_model=model, device=torch.device("cpu"))
+    model.to(device)
+    s, v = value_targets(states.to(device), rewards.to(device), dones.to(device), infos.to(device), mode == "il", gbar,
+                         target_model=model, device=device)
     want_v = np.concatenate([g["%s_e%d_values" % (mode, e)] for e in range(3)])
     want_s = np.concatenate([g["%s_e%d_mem_states" % (mode, e)] for e in range(3)])
-    assert tuple(s.shape) == want_s.shape and np.array_equal(s.numpy(), want_s)         # (env, time) order = episode order
-    np.testing.assert_allclose(v.numpy(), want_v, rtol=0, atol=1e-6)
+    assert tuple(s.shape) == want_s.shape and np.array_equal(s.cpu().numpy(), want_s)   # (env, time) order = episode order
+    np.testing.assert_allclose(v.cpu().numpy(), want_v, rtol=0, atol=atol)
+    return float(np.abs(v.cpu().numpy() - want_v).max())
+
+
+@pytest.mark.parametrize("mode", ["rl", "il"])
+def test_value_targets_match_reference_update_memory(mode, golden_dir):
+    check_value_targets_against_reference(mode, golden_dir, torch.device("cpu"), 1e-6)
 
 
 def _dp_unequal_worker(rank, ws, port, out_dir):

@@ -73,3 +73,24 @@ def test_imitation_then_reinforcement_learning_loop():
     sarl.set_phase("val"); sarl.set_epsilon(0.0)
     _, sr2, _, _ = ex.run_k_episodes(E, "val")
     assert sr2 > sr0 + 0.3
+
+
+@pytest.mark.parametrize("mode", ["batch", "epoch"])
+def test_trainer_steps_match_reference_trainer_on_device(mode, golden_dir):
+    """SURVEY 8f f2 on the device: utils/trainer.py with model, replay memory and optimiser on cuda:0 against the
+    REAL reference's Trainer (crowd_nav/utils/trainer.py:64-82; g10_trainer.npz).  Tolerance 2e-6 on weights and
+    losses (the CPU run holds 1e-6; rocBLAS sums the float32 dot products in another order)."""
+    import torch
+    from tests.test_training_cpu import check_trainer_against_reference
+    worst = check_trainer_against_reference(mode, golden_dir, torch.device("cuda", 0), 2e-6)
+    print("trainer on device, mode %s: max |w - w_ref| = %.3g" % (mode, worst))
+
+
+@pytest.mark.parametrize("mode", ["rl", "il"])
+def test_value_targets_match_reference_update_memory_on_device(mode, golden_dir):
+    """rollout.value_targets on cuda:0 against the reference's Explorer.update_memory (explorer.py:153-186;
+    g12_update_memory.npz): stored states exact, values to 2e-6."""
+    import torch
+    from tests.test_training_cpu import check_value_targets_against_reference
+    worst = check_value_targets_against_reference(mode, golden_dir, torch.device("cuda", 0), 2e-6)
+    print("value targets on device, mode %s: max |v - v_ref| = %.3g" % (mode, worst))

@@ -6,5 +6,5 @@ VARS=$1; shift
 for v in $VARS; do
   echo "== $v"
   W=$(echo $v | sed "s/.*w\([0-9]*\)$/\1/")
-  MCN_POOL_WAVES=${W:-12} MCN_HIP_LIB=$ROOT/modelcrowdnav_amd/csrc/build_ab/$v/libmcn_hip.so timeout -k 10 120 python3 "$ROOT/$1" "${@:2}" 2>&1 | grep -v amdgpu.ids | tail -6 || exit 1
+  MCN_POOL_WAVES=${W:-16} MCN_HIP_LIB=$ROOT/modelcrowdnav_amd/csrc/build_ab/$v/libmcn_hip.so timeout -k 10 120 python3 "$ROOT/$1" "${@:2}" 2>&1 | grep -v amdgpu.ids | tail -6 || exit 1
 done

@@ -1,12 +1,18 @@
 #!/usr/bin/env python3
-"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --output-format csv) over the same command into the
+"""Turn pairs of rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --output-format csv) over the same command into the
 per-kernel HBM-traffic summary committed under profiles/.
 
-    python tools/pmc_summary.py <fetch_dir> <write_dir> <out.json> [--steps-per-launch S]
+    python tools/pmc_summary.py <out.json> --run <fetch_dir>:<write_dir>:<humans>:<E1+E2+...>:<steps_per_launch> [--run ...]
 
-Counter unit: KB per dispatch.  Per /opt/skills/guides/MI355X_MICROARCH.md ("HBM"), FETCH_SIZE on gfx950 reports
-half of the bytes of wide coalesced loads, so reads are doubled; WRITE_SIZE is taken as is.  Only mcn:: kernels are
-kept; launches are grouped by (kernel name, grid size) and averaged.
+One --run per profiled command: what the command stepped (humans per env, the batch sizes it ran, steps per launch for
+mcn_env_rollout).  Counter unit: KB per dispatch.  Per /opt/skills/guides/MI355X_MICROARCH.md ("HBM"), FETCH_SIZE on
+gfx950 reports half of the bytes of wide coalesced loads, so reads are doubled; WRITE_SIZE is taken as is.  Only mcn::
+kernels are kept; launches are grouped by (kernel name, grid size) and averaged.
+
+Every entry says which kernel FAMILY it is (env_pair_kernel / env_step_kernel / env_step_quad_kernel /
+env_rollout_quad_kernel / sarl_value_kernel / sgan_*_kernel), which human-policy MODE that instantiation computes
+(parsed from the template arguments, never guessed from a substring) and on how many envs of how many humans it ran
+(the run's batch size whose lane count matches the launch's grid); bench.py matches on exactly those.
 """
 import argparse
 import csv
@@ -18,6 +24,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (classify_kernel, the byte accounting)
 
 
 def collect(d, counter):
@@ -32,59 +39,74 @@ def collect(d, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
-def envs_of(name, grid, wg):
-    """Batch size from the launch geometry of the env kernels (see the launchers in csrc/)."""
-    import re
-    m = re.search(r"env_(?:step|rollout)_quad_kernel<(\d+), (\d+)", name)
-    if m:                                   # one wavefront (two when split) per 64 // (4 N) envs
-        nt = int(m.group(1))
-        return None, grid // wg, 64 // (4 * nt)
-    return None, None, None
+def match_envs(grid, humans, lanes_per_human, sizes):
+    """The run's batch size this launch covered: grid = E x humans x lanes-per-human, padded to whole wavefronts
+    (at most 64 / 60 for the layouts in csrc/) and workgroups."""
+    for E in sizes:
+        need = E * humans * lanes_per_human
+        if need <= grid <= 1.4 * need + 1024:
+            return E
+    return None
+
+
+def summarise(run, algorithmic):
+    fdir, wdir, humans, sizes, spl = run
+    fetch, n_f = collect(fdir, "FETCH_SIZE")
+    write, _ = collect(wdir, "WRITE_SIZE")
+    out = []
+    for key in sorted(fetch, key=lambda k: (k[1], k[0])):
+        name, grid, wg = key
+        if key not in write:
+            continue
+        c = bench.classify_kernel(name, humans)
+        if c is None:
+            continue
+        fam, n, mode, lph = c
+        if lph is None:                      # network kernels: one batch size per run, grid is not a lane-per-human count
+            E = sizes[0] if len(sizes) == 1 else None
+        else:
+            E = match_envs(grid, n, lph, sizes)
+        if E is None:
+            continue
+        S = spl if fam == "env_rollout_quad_kernel" else 1
+        rd, wr = 2.0 * fetch[key] * 1024.0, write[key] * 1024.0
+        e = {"kernel": name, "family": fam, "mode": mode, "humans": n, "envs": E, "steps_per_launch": S,
+             "grid_threads": grid, "workgroup": wg, "launches_averaged": n_f[key],
+             "FETCH_SIZE_KB": round(fetch[key], 1), "WRITE_SIZE_KB": round(write[key], 1),
+             "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr), "traffic_bytes_per_launch": int(rd + wr)}
+        if mode is not None:
+            alg = algorithmic(n, mode == "given") * E * S
+            e["what"] = {"given": "pairwise-only (given velocities, 566-B accounting at 5 humans)",
+                         "orca": "fused ORCA step", "linear": "linear humans"}[mode] + (", %d steps per launch" % S if S > 1 else "")
+            e["algorithmic_bytes_per_launch"] = int(alg)
+            e["traffic_over_algorithmic"] = round((rd + wr) / alg, 4)
+        out.append(e)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("fetch_dir"); ap.add_argument("write_dir"); ap.add_argument("out")
-    ap.add_argument("--humans", type=int, default=5)
-    ap.add_argument("--envs", type=str, default="", help="kernel-substring=envs[,..] overrides, e.g. 'env_step_kernel<256=1048576'")
-    ap.add_argument("--steps-per-launch", type=int, default=1, help="steps one env_rollout launch advances")
+    ap.add_argument("out")
+    ap.add_argument("--run", action="append", required=True,
+                    help="fetch_dir:write_dir:humans:E1+E2+..:steps_per_launch")
     ap.add_argument("--note", default="")
+    ap.add_argument("--only", default="", help="comma list of kernel-name substrings to keep (default: all mcn:: kernels)")
     a = ap.parse_args()
-    import bench
-    fetch, n_f = collect(a.fetch_dir, "FETCH_SIZE")
-    write, _ = collect(a.write_dir, "WRITE_SIZE")
-    over = dict(x.split("=") for x in a.envs.split(",") if x)
+    alg = lambda n, given: bench.pairwise_bytes_per_env_step(n) if given else bench.algorithmic_bytes_per_env_step(n)
     kernels = []
-    for key in sorted(fetch, key=lambda k: (k[1], k[0])):
-        name, grid, wg = key
-        if key not in write or "env_" not in name:
-            continue
-        E = None
-        for sub, val in over.items():
-            if sub in name:
-                E = int(val)
-        _, blocks, per = envs_of(name, grid, wg)
-        if E is None and blocks is not None:
-            E = blocks * per                          # upper bound; exact when E divides evenly
-        if E is None:
-            E = grid // a.humans                      # lane-per-human kernels: about one lane per human
-        given = ", 2, " in name                       # MODE template argument = MCN_HUMANS_GIVEN
-        S = a.steps_per_launch if "rollout" in name else 1
-        alg = (bench.pairwise_bytes_per_env_step(a.humans) if given else bench.algorithmic_bytes_per_env_step(a.humans)) * E * S
-        rd, wr = 2.0 * fetch[key] * 1024.0, write[key] * 1024.0
-        kernels.append({
-            "kernel": name, "grid_threads": grid, "workgroup": wg, "launches_averaged": n_f[key], "envs": E,
-            "steps_per_launch": S,
-            "what": ("pairwise-only (given velocities)" if given else "fused ORCA step") + (", %d steps per launch" % S if S > 1 else ""),
-            "FETCH_SIZE_KB": round(fetch[key], 1), "WRITE_SIZE_KB": round(write[key], 1),
-            "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr), "traffic_bytes_per_launch": int(rd + wr),
-            "algorithmic_bytes_per_launch": int(alg), "traffic_over_algorithmic": round((rd + wr) / alg, 4)})
+    for r in a.run:
+        fdir, wdir, humans, sizes, spl = r.split(":")
+        kernels += summarise((fdir, wdir, int(humans), [int(x) for x in sizes.split("+")], int(spl)), alg)
+    if a.only:
+        kernels = [k for k in kernels if any(sub in k["kernel"] for sub in a.only.split(","))]
     json.dump({"note": a.note or "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, --output-format csv; "
                "counter unit KB, averaged over the launches of each (kernel, grid); FETCH_SIZE doubled per "
                "MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced loads), WRITE_SIZE as is.",
                "kernels": kernels}, open(a.out, "w"), indent=1)
     for k in kernels:
-        print("%-60s E=%8d S=%3d traffic/alg = %.3f" % (k["kernel"][:60], k["envs"], k["steps_per_launch"], k["traffic_over_algorithmic"]))
+        print("%-58s %-6s N=%2d E=%8d S=%4d  %10.1f KB  traffic/alg = %s" % (
+            k["kernel"][:58], k["mode"], k["humans"], k["envs"], k["steps_per_launch"],
+            k["traffic_bytes_per_launch"] / 1024.0, k.get("traffic_over_algorithmic")))
 
 
 if __name__ == "__main__":

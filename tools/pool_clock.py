@@ -38,7 +38,7 @@ def main():
         for _ in range(200):
             world(pos)
         torch.cuda.synchronize()
-    W = int(os.environ.get("MCN_POOL_WAVES", "12"))          # must match the library's build
+    W = int(os.environ.get("MCN_POOL_WAVES", "16"))          # must match the library's build
     buf = np.zeros((256 * W, 8), np.uint64)
     n = fn(buf.ctypes.data, buf.nbytes)
     assert n > 0

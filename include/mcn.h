@@ -237,7 +237,8 @@ typedef struct mcn_sarl_net {
     const float *w_m3d, *b_m3d;   /* mlp3.6       100 -> 1   */
 } mcn_sarl_net;
 
-/* Bytes of device workspace mcn_sarl_lookahead needs for (E, N, A). */
+/* Bytes of device workspace mcn_sarl_lookahead needs for (E, N, A): one slot per RESIDENT wavefront of the persistent
+ * grid (at most 2 048), N x 7 KiB each -- 72 MB at N = 5, whatever E. */
 int64_t mcn_sarl_workspace_bytes(int32_t E, int32_t N, int32_t A);
 
 /*
@@ -266,6 +267,19 @@ int mcn_sarl_lookahead_env(const mcn_sarl_net *net, const mcn_env_state *st, con
                            double *values, int32_t *best, double *best_val, float *attention,
                            const double *next_hpos, const double *next_hvel, const double *rewards,
                            int32_t E, int32_t N, void *stream);
+
+/*
+ * mcn_sarl_predict -- the look-ahead AND the action MultiHumanRL.predict returns (multi_human_rl.py:22-23,53-63), for
+ * every env, with no host round trip: action_out[e] = actions[best[e]], or (0, 0) where best[e] == -1 (robot on its
+ * goal) or every value is NaN (best[e] < 0 with best_val = -inf: "Value network is not well trained", the caller's
+ * error).  next_hpos / next_hvel / rewards: all NULL (mcn_sarl_lookahead's propagate + compute_reward) or all set
+ * (mcn_sarl_lookahead_env's `query_env` form).  action_out: [E][2] device out.  Everything else as above.
+ */
+int mcn_sarl_predict(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int32_t A,
+                     double time_step, double gamma_pow, int32_t kinematics, void *workspace,
+                     double *values, int32_t *best, double *best_val, float *attention,
+                     const double *next_hpos, const double *next_hvel, const double *rewards,
+                     double *action_out, int32_t E, int32_t N, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Social-GAN one-step world model (crowd_nav/policy/world_model.py:134-268, sgan/models.py:501-553).

@@ -20,8 +20,12 @@
 //   lanes, which makes the reductions over humans (global-state mean, softmax denominator, pooled
 //   feature) plain per-lane register arithmetic.
 //
-//   pass 1, per human: features -> mlp1 (13->150->100); keep mlp1 output in a per-wave workspace
-//                      (L2-resident), accumulate the mean.
+//   pass 1, per human: features -> mlp1 (13->150->100); park mlp1's output in the wavefront's workspace slot,
+//                      accumulate the mean.  The grid is PERSISTENT (at most kSarlMaxBlocks workgroups, two per CU,
+//                      each walking over its share of the 16-pair tiles), so the workspace is indexed by resident
+//                      wavefront, not by tile: 2 048 slots x N x 7 KiB = 72 MB at N = 5 (143 MB at N = 10) whatever
+//                      the batch -- it lives in the 256 MB Infinity Cache between the two passes instead of making a
+//                      round trip through HBM (0.74 / 1.49 GB per look-ahead when it was indexed by tile).
 //   pass 2, per human: attention (200->100->100->1) with the global half folded into the accumulator
 //                      init, exp, mlp2 (100->100->50), pooled += e * mlp2_out.
 //   tail:              mlp3 (56->150->100->100->1), value, store.
@@ -68,7 +72,8 @@ struct SarlParams {
     const double *next_hpos, *next_hvel;                          // [E*N][2]
     const double *reward_in;                                      // [E*A]
     const double *actions;                                // [A][2]
-    float4 *workspace;                                    // [waves][N][T100][64] float4
+    float4 *workspace;                                    // [resident waves][N][T100][64] float4
+    long ngroups;                                         // 4-tile groups (one per workgroup pass) = ceil(tiles / 4)
     double *values;                                       // [E*A]
     float *attention;                                     // [E*A*N] or NULL
     int E, N, A, kinematics;
@@ -82,19 +87,27 @@ constexpr int kSarlWaves = kStageThreads / 64;     // 8 wavefronts share one LDS
 __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl_value_kernel(const SarlParams p)
 {
     __shared__ float4 s_stage[2 * (kStageFloat4 + kStageBias)];
-    const WeightStage S{s_stage, (int)threadIdx.x};
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const long gw = (long)blockIdx.x * kSarlWaves + wave;       // global wave id
-    const int j = lane & 15, q = lane >> 4;
     const long npairs = (long)p.E * p.A;
-    const long pair0 = gw * 16;
+    const int N = p.N;
+    // every wavefront of the workgroup runs the same number of passes (the weight-staging barriers are collective)
+#pragma unroll 1
+  for (long grp = blockIdx.x; grp < p.ngroups; grp += gridDim.x) {
+    // the thread id is made opaque once per pass: everything derived from it (the per-lane addresses of every weight
+    // chunk of every layer) would otherwise be hoisted out of this loop and live -- and spill -- across it
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const WeightStage S{s_stage, tid};
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    // this wavefront's workspace slot: by resident wavefront (persistent grid), reused for every tile it walks over
+    float4 *const ws = p.workspace + ((long)blockIdx.x * kSarlWaves + wave) * (long)N * T100 * 64;
+    const long pair0 = (grp * kSarlWaves + wave) * 16;
     // no early exit: every wavefront of the workgroup takes part in the weight staging barriers
     long pair = pair0 + j;
     const bool valid = pair < npairs;
     if (!valid) pair = npairs - 1;
     const int e = (int)(pair / p.A), a = (int)(pair - (long)e * p.A);
-    const int N = p.N;
     // pedestrians this pair's env shows to the policy; the loops below stay N long for the whole workgroup (they
     // contain the weight-staging barriers) and absent slots are masked out of every reduction
     int ne = N;
@@ -128,14 +141,17 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
     const float f_vx = svx * cr + svy * sr;
     const float f_vy = svy * cr - svx * sr;
 
-    float4 *ws = p.workspace + gw * (long)N * T100 * 64;
-
     // ---- pass 1: mlp1 per human, global-state sum, reward ----
     f32x4 gsum[T100];
 #pragma unroll
     for (int t = 0; t < T100; ++t) gsum[t] = (f32x4){0, 0, 0, 0};
     double dmin = INFINITY;
     for (int i = 0; i < N; ++i) {
+        // per-pass opaque copy of the thread id: the staging addresses of this pass's layers are re-derived here
+        // (a few integer instructions) instead of being hoisted out of the loop as ~30 live 64-bit values
+        int tid_i = tid;
+        asm volatile("" : "+v"(tid_i));
+        const WeightStage S{s_stage, tid_i};
         const long ha = (long)e * N + i;
         const double2 hp = reinterpret_cast<const double2 *>(p.hpos)[ha];
         const double2 hv = reinterpret_cast<const double2 *>(p.hvel)[ha];
@@ -200,6 +216,9 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
     for (int t = 0; t < T50; ++t) pooled[t] = (f32x4){0, 0, 0, 0};
     float denom = 0.0f;
     for (int i = 0; i < N; ++i) {
+        int tid_i = tid;
+        asm volatile("" : "+v"(tid_i));
+        const WeightStage S{s_stage, tid_i};
         f32x4 h2[T100];
 #pragma unroll
         for (int t = 0; t < T100; ++t) {
@@ -254,6 +273,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
     if (p.attention && valid && q == 0) {
         for (int i = 0; i < N; ++i) p.attention[pair * N + i] /= denom;
     }
+  }
 }
 
 // Strict-'>' argmax over the A candidate values of each env (multi_human_rl.py:53-55: the first maximum
@@ -261,7 +281,8 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
 // returns the zero action without evaluating anything.
 __global__ __launch_bounds__(64) void sarl_argmax_kernel(const double *__restrict__ values, const double *rpos,
                                                        const double *rgoal, const double *rrad, int E, int A,
-                                                       int32_t *__restrict__ best, double *__restrict__ best_val)
+                                                       int32_t *__restrict__ best, double *__restrict__ best_val,
+                                                       const double *__restrict__ actions, double *__restrict__ action_out)
 {
     const int e = blockIdx.x;
     const int lane = threadIdx.x;
@@ -283,18 +304,29 @@ __global__ __launch_bounds__(64) void sarl_argmax_kernel(const double *__restric
         const bool reached = norm2d(rp.y - rg.y, rp.x - rg.x) < rrad[e];
         best[e] = reached ? -1 : bi;
         best_val[e] = bv;
+        if (action_out) {
+            // what MultiHumanRL.predict returns: the table row of the best value, the zero action on the goal
+            // (multi_human_rl.py:22-23) -- and also when every value is NaN (bi < 0: the host raises, as the reference)
+            const bool zero = reached || bi < 0;
+            const double2 act = reinterpret_cast<const double2 *>(actions)[zero ? 0 : bi];
+            reinterpret_cast<double2 *>(action_out)[e] = zero ? make_double2(0.0, 0.0) : act;
+        }
     }
 }
 
-int launch_sarl(const SarlParams &p, int32_t *best, double *best_val, hipStream_t stream)
+// Persistent grid: two 4-wave workgroups per CU on the 256 CUs of an MI355X (fewer CUs: more passes, same result).
+constexpr int kSarlMaxBlocks = (kSarlWaves >= 8 ? 1 : 2) * 256;
+
+int launch_sarl(SarlParams &p, int32_t *best, double *best_val, double *action_out, hipStream_t stream)
 {
     const long npairs = (long)p.E * p.A;
     const long waves = (npairs + 15) / 16;
-    const int blocks = (int)((waves + kSarlWaves - 1) / kSarlWaves);
+    p.ngroups = (waves + kSarlWaves - 1) / kSarlWaves;
+    const int blocks = (int)(p.ngroups < kSarlMaxBlocks ? p.ngroups : kSarlMaxBlocks);
     hipLaunchKernelGGL(sarl_value_kernel, dim3(blocks), dim3(kSarlWaves * 64), 0, stream, p);
     if (best) {
         hipLaunchKernelGGL(sarl_argmax_kernel, dim3(p.E), dim3(64), 0, stream, p.values, p.rpos, p.rgoal, p.rrad,
-                           p.E, p.A, best, best_val);
+                           p.E, p.A, best, best_val, p.actions, action_out);
     }
     return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
 }
@@ -302,7 +334,7 @@ int launch_sarl(const SarlParams &p, int32_t *best, double *best_val, hipStream_
 int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int A, double dt,
                   double gamma_pow, int kinematics, void *workspace, double *values, int32_t *best, double *best_val,
                   float *attention, const double *next_hpos, const double *next_hvel, const double *reward_in,
-                  int E, int N, hipStream_t stream)
+                  double *action_out, int E, int N, hipStream_t stream)
 {
     SarlParams p;
     const float4 *const *src = reinterpret_cast<const float4 *const *>(net);
@@ -315,14 +347,15 @@ int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double
     p.actions = actions; p.workspace = reinterpret_cast<float4 *>(workspace);
     p.values = values; p.attention = attention;
     p.E = E; p.N = N; p.A = A; p.kinematics = kinematics; p.dt = dt; p.gamma_pow = gamma_pow;
-    return launch_sarl(p, best, best_val, stream);
+    return launch_sarl(p, best, best_val, action_out, stream);
 }
 
 long sarl_workspace_float4s(int E, int N, int A)
 {
     const long waves = ((long)E * A + 15) / 16;
-    const long wpad = (waves + kSarlWaves - 1) / kSarlWaves * kSarlWaves;
-    return wpad * (long)N * T100 * 64;
+    long groups = (waves + kSarlWaves - 1) / kSarlWaves;
+    if (groups > kSarlMaxBlocks) groups = kSarlMaxBlocks;          // one slot per RESIDENT wavefront
+    return groups * kSarlWaves * (long)N * T100 * 64;
 }
 
 }  // namespace mcn

@@ -37,9 +37,10 @@ class MultiHumanRL(CADRL):
         raise NotImplementedError
 
     def _lookahead(self, st, E, N, dev, want_attention=False, env_next=None):
-        """Launch mcn_sarl_lookahead on an EnvState struct; returns (values[E,A], best[E], best_val[E], att).
-        env_next = (next_hpos [E,N,2], next_hvel [E,N,2], rewards [E,A]): the `query_env` form
-        (mcn_sarl_lookahead_env) -- the env's look-ahead states and rewards instead of propagate + compute_reward."""
+        """Launch mcn_sarl_predict on an EnvState struct; returns (values[E,A], best[E], best_val[E], att); the chosen
+        actions [E,2] (table row of `best`, zero where the robot stands on its goal) are left in self._bufs["action"].
+        env_next = (next_hpos [E,N,2], next_hvel [E,N,2], rewards [E,A]): the `query_env` form -- the env's
+        look-ahead states and rewards instead of propagate + compute_reward."""
         if self.action_space is None:
             raise RuntimeError("action space not built")
         A = len(self.action_space)
@@ -52,6 +53,7 @@ class MultiHumanRL(CADRL):
                 "values": torch.empty(E, A, dtype=torch.float64, device=dev),
                 "best": torch.empty(E, dtype=torch.int32, device=dev),
                 "best_val": torch.empty(E, dtype=torch.float64, device=dev),
+                "action": torch.empty(E, 2, dtype=torch.float64, device=dev),
                 "table": torch.from_numpy(np.ascontiguousarray(self._action_table)).to(dev),
                 "att": None,
             }
@@ -61,18 +63,13 @@ class MultiHumanRL(CADRL):
         net = self._packed(dev)
         kin = _hip.KIN_UNICYCLE if self.kinematics == "unicycle" else _hip.KIN_HOLONOMIC
         gamma_pow = pow(self.gamma, self.time_step * self._v_pref)       # multi_human_rl.py:52
-        if env_next is None:
-            rc = _hip.lib.mcn_sarl_lookahead(C.byref(net), st, _hip.ptr(b["table"]), A, float(self.time_step), gamma_pow, kin,
-                                             _hip.ptr(b["ws"]), _hip.ptr(b["values"]), _hip.ptr(b["best"]),
-                                             _hip.ptr(b["best_val"]), _hip.ptr(b["att"]) if want_attention else None,
-                                             E, N, _hip.stream_ptr(dev))
-        else:
-            npos, nvel, rew = env_next
-            rc = _hip.lib.mcn_sarl_lookahead_env(C.byref(net), st, _hip.ptr(b["table"]), A, float(self.time_step), gamma_pow,
-                                                 kin, _hip.ptr(b["ws"]), _hip.ptr(b["values"]), _hip.ptr(b["best"]),
-                                                 _hip.ptr(b["best_val"]), _hip.ptr(b["att"]) if want_attention else None,
-                                                 _hip.ptr(npos), _hip.ptr(nvel), _hip.ptr(rew), E, N, _hip.stream_ptr(dev))
-        _hip.check(rc, "mcn_sarl_lookahead")
+        npos, nvel, rew = env_next if env_next is not None else (None, None, None)
+        rc = _hip.lib.mcn_sarl_predict(C.byref(net), st, _hip.ptr(b["table"]), A, float(self.time_step), gamma_pow, kin,
+                                       _hip.ptr(b["ws"]), _hip.ptr(b["values"]), _hip.ptr(b["best"]),
+                                       _hip.ptr(b["best_val"]), _hip.ptr(b["att"]) if want_attention else None,
+                                       _hip.ptr(npos), _hip.ptr(nvel), _hip.ptr(rew), _hip.ptr(b["action"]),
+                                       E, N, _hip.stream_ptr(dev))
+        _hip.check(rc, "mcn_sarl_predict")
         return b["values"], b["best"], b["best_val"], b["att"]
 
     def _query_env(self, venv):
@@ -187,7 +184,8 @@ class MultiHumanRL(CADRL):
         one draw per env per step from torch's device generator) -- `best` is -2 for those envs.
 
         Returns (actions [E,2] float64 device tensor, best [E] int32; -1 where the robot already
-        stands on its goal and the zero action is returned, multi_human_rl.py:22-23).
+        stands on its goal and the zero action is returned, multi_human_rl.py:22-23).  Both (and `values`) are the
+        policy's own output buffers, written by the look-ahead launch: valid until the next predict_batch call.
         hcount ([E] int32 device tensor, optional): env e shows only its first hcount[e] pedestrians to the policy
         (the reference simply hands `predict` a shorter list, e.g. datagen.py:347-363)."""
         if self.action_space is None:
@@ -218,8 +216,7 @@ class MultiHumanRL(CADRL):
             idx = torch.where(explore, ridx, best.clamp(min=0)).long()
             actions = table[idx] * (best != -1).unsqueeze(1).to(table.dtype)
         else:
-            idx = best.clamp(min=0).long()
-            actions = table[idx] * (best >= 0).unsqueeze(1).to(table.dtype)
+            actions = self._bufs["action"]          # written by the look-ahead's argmax kernel: no torch launches
         if want_values:
             return actions, best, values
         return actions, best

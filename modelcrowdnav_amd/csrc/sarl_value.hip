@@ -315,7 +315,10 @@ __global__ __launch_bounds__(64) void sarl_argmax_kernel(const double *__restric
 }
 
 // Persistent grid: two 4-wave workgroups per CU on the 256 CUs of an MI355X (fewer CUs: more passes, same result).
-constexpr int kSarlMaxBlocks = (kSarlWaves >= 8 ? 1 : 2) * 256;
+#ifndef MCN_SARL_MAX_BLOCKS
+#define MCN_SARL_MAX_BLOCKS ((kSarlWaves >= 8 ? 1 : 2) * 256)
+#endif
+constexpr int kSarlMaxBlocks = MCN_SARL_MAX_BLOCKS;     // A/B: a huge value = one workgroup per 4-tile group, workspace by tile
 
 int launch_sarl(SarlParams &p, int32_t *best, double *best_val, double *action_out, hipStream_t stream)
 {

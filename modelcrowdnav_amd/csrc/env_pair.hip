@@ -33,6 +33,14 @@ __device__ __forceinline__ long long d2ll(double v) { return __builtin_bit_cast(
 __device__ __forceinline__ double ll2d(long long v) { return __builtin_bit_cast(double, v); }
 
 constexpr int kPairDiscMax = 128;
+// where the per-step discount factor gamma^(t v_pref) of the Explorer return comes from (A/B switch):
+//   0  every wavefront copies the table to its own LDS slab at entry (2 global loads + 2 LDS stores per wavefront)
+//   1  one copy per workgroup + a workgroup barrier
+//   2  no copy: a reward of exactly 0 adds nothing to the return (x + d * 0 == x for every finite d, and the ladder's
+//      zero is +0), so only lanes whose step earned a reward fetch their ONE table entry from L2
+#ifndef MCN_PAIR_DISC
+#define MCN_PAIR_DISC 2
+#endif
 
 template <int NT>
 __global__ __launch_bounds__(256) void env_pair_kernel(const StepParams p)
@@ -42,7 +50,7 @@ __global__ __launch_bounds__(256) void env_pair_kernel(const StepParams p)
     __shared__ double2 s_piece[WPB][G][5];
     __shared__ double s_small[WPB][G][2];
     __shared__ double s_cd[WPB][64];
-    __shared__ double s_disc[WPB][kPairDiscMax];
+    __shared__ double s_disc[MCN_PAIR_DISC == 0 ? WPB : 1][MCN_PAIR_DISC == 2 ? 1 : kPairDiscMax];
 #ifdef MCN_DIAG
     if (p.debug_noop) return;
 #endif
@@ -84,10 +92,14 @@ __global__ __launch_bounds__(256) void env_pair_kernel(const StepParams p)
         const double *src = h == 0 ? p.st.rrad : p.st.gtime;
         if (h < 2) small = src[eb];
     }
-    if (has_state) {
+    if (MCN_PAIR_DISC == 0 && has_state) {
         const int len = ro.disc_len;
         s_disc[wave][lane] = lane < len ? ro.disc_table[lane] : 0.0;
         s_disc[wave][lane + 64] = lane + 64 < len ? ro.disc_table[lane + 64] : 0.0;
+    }
+    if (MCN_PAIR_DISC == 1 && has_state) {
+        const int t = threadIdx.x;
+        if (t < kPairDiscMax) s_disc[0][t] = t < ro.disc_len ? ro.disc_table[t] : 0.0;
     }
 
     // ---- exchange inside the wavefront ----
@@ -109,6 +121,7 @@ __global__ __launch_bounds__(256) void env_pair_kernel(const StepParams p)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (MCN_PAIR_DISC == 1) __syncthreads();              // the workgroup's discount table is in place
     double dmin = INFINITY;
     {
         const int l0 = (g < G ? g : 0) * NT;
@@ -138,7 +151,9 @@ __global__ __launch_bounds__(256) void env_pair_kernel(const StepParams p)
         double danger_sum = rs_hi.y;
         case_g = next_case;
         const int di = ep_steps < ro.disc_len ? ep_steps : ro.disc_len - 1;
-        const double ep_disc = s_disc[wave][di];
+        double ep_disc = 0.0;
+        if (MCN_PAIR_DISC == 2) { if (rew != 0.0) ep_disc = ro.disc_table[di]; }
+        else ep_disc = s_disc[MCN_PAIR_DISC == 0 ? wave : 0][di];
         if (inf == MCN_INFO_DANGER && (ro.danger_episodes <= 0 ||
             fin_count < ro.danger_episodes - ((ro.danger_short_from > 0 && e >= ro.danger_short_from - 1) ? 1 : 0))) {
             danger_count += 1; danger_sum += dmin;

@@ -97,7 +97,15 @@ typedef struct mcn_env_out {
     double  *human_act;   /* [E*N][2] velocity each human chose, or NULL */
     double  *nobs_pos;    /* [E*N][2] next observable positions  (update == 0 only) */
     double  *nobs_vel;    /* [E*N][2] next observable velocities (update == 0 only) */
+    void    *lp3_queue;   /* optional: mcn_env_lp3_queue_bytes(E, N) bytes of device memory, zero-filled ONCE by the caller
+                           * and then owned by the env (the kernels keep its header consistent), or NULL.  With a queue,
+                           * large ORCA batches of <= 10 humans solve RVO2's rare linearProgram3 in a second, dense launch
+                           * (one parked problem per lane) instead of inside the step kernel, where one or two lanes of a
+                           * wavefront would run it while the others wait.  Same results bit for bit. */
 } mcn_env_out;
+
+/* Bytes of mcn_env_out.lp3_queue for E envs of N humans (0 when N is outside the deferred path's range). */
+int64_t mcn_env_lp3_queue_bytes(int32_t E, int32_t N);
 
 /*
  * Optional fused bookkeeping of Explorer.run_k_episodes (crowd_nav/utils/explorer.py:54-125)
@@ -323,7 +331,7 @@ int mcn_sgan_step(const mcn_sgan_net *net, double *hist, int32_t push_slot, int3
  * Dispatch overrides (host, process-wide, not stream-ordered; for tests and tuning).  Every env-step arithmetic
  * exists in several kernel decompositions with bit-identical results; by default the entry points pick one from
  * the batch shape.  -1 = automatic.  The MCN_FORCE_GENERIC / MCN_QUAD_MAX_ENVS / MCN_QUAD_SPLIT /
- * MCN_ROLLOUT_FUSED / MCN_ROLLOUT_SPLIT / MCN_PAIR_STREAM environment variables give the initial values and are read once, at
+ * MCN_ROLLOUT_FUSED / MCN_ROLLOUT_SPLIT / MCN_PAIR_STREAM / MCN_STEP_BLOCK / MCN_LP3_DEFER environment variables give the initial values and are read once, at
  * the first launch; no entry point calls getenv after that.
  */
 typedef struct mcn_tuning {
@@ -335,6 +343,8 @@ typedef struct mcn_tuning {
     int32_t step_block;      /* lane-per-human step kernels: workgroup of 64 or 256 lanes (-1: 64 up to 4096 wavefronts, 256 above) */
     int32_t diag_noop;       /* DIAGNOSTIC build only (make stamp): env kernels return at entry; MCN_EINVAL otherwise */
     int32_t pair_stream;     /* given-velocity step: streaming kernel (env_pair.hip) 1 wherever it applies / 0 never */
+    int32_t lp3_defer;       /* lane-per-human ORCA kernels with mcn_env_out.lp3_queue set: park the 3-D LPs for a second,
+                              * dense launch (1) or solve them in the step kernel (0); -1: defer above 2048 wavefronts */
 } mcn_tuning;
 
 /* NULL restores the initial values.  Returns MCN_EINVAL for out-of-range fields.  The settings are one unsynchronised

@@ -39,7 +39,7 @@ class EnvState(C.Structure):
 
 
 class EnvOut(C.Structure):
-    _fields_ = [(k, _vp) for k in ("rec", "human_act", "nobs_pos", "nobs_vel")]
+    _fields_ = [(k, _vp) for k in ("rec", "human_act", "nobs_pos", "nobs_vel", "lp3_queue")]
 
 
 class StepRec(C.Structure):
@@ -92,7 +92,7 @@ RULE_CIRCLE, RULE_SQUARE = 0, 1
 class Tuning(C.Structure):
     """mcn_tuning: dispatch overrides, -1 = automatic."""
     _fields_ = [(k, _i) for k in ("force_generic", "quad_max_envs", "quad_split", "rollout_fused", "rollout_split",
-                                  "step_block", "diag_noop", "pair_stream")]
+                                  "step_block", "diag_noop", "pair_stream", "lp3_defer")]
 
 
 class McnError(RuntimeError):
@@ -109,6 +109,8 @@ def _load():
     lib.mcn_env_step.argtypes = [C.POINTER(EnvCfg), C.POINTER(EnvState), _vp, _vp, C.POINTER(EnvOut),
                                  C.POINTER(Rollout), _i, _i, _i, _vp]
     lib.mcn_env_step.restype = C.c_int
+    lib.mcn_env_lp3_queue_bytes.argtypes = [_i, _i]
+    lib.mcn_env_lp3_queue_bytes.restype = C.c_int64
     lib.mcn_env_rollout.argtypes = [C.POINTER(EnvCfg), C.POINTER(EnvState), _vp, _i, C.POINTER(EnvOut),
                                     C.POINTER(Rollout), _i, _i, _vp]
     lib.mcn_env_rollout.restype = C.c_int
@@ -144,7 +146,7 @@ def _load():
 lib = _load()
 
 # every symbol include/mcn.h declares; tests/test_abi.py checks the .so exports each one
-EXPORTED = ["mcn_version", "mcn_set_tuning", "mcn_get_tuning", "mcn_env_step", "mcn_env_rollout", "mcn_scenario_pool", "mcn_orca_batch", "mcn_pack_linear", "mcn_sarl_workspace_bytes",
+EXPORTED = ["mcn_version", "mcn_set_tuning", "mcn_get_tuning", "mcn_env_step", "mcn_env_lp3_queue_bytes", "mcn_env_rollout", "mcn_scenario_pool", "mcn_orca_batch", "mcn_pack_linear", "mcn_sarl_workspace_bytes",
             "mcn_sarl_lookahead", "mcn_sarl_lookahead_env", "mcn_sarl_predict", "mcn_sgan_workspace_bytes", "mcn_sgan_step"]
 
 

@@ -27,6 +27,7 @@
 #include "orca_coop.hpp"
 #include "env_step_params.hpp"
 #include "env_common.hpp"
+#include "lp3_queue.hpp"
 
 namespace mcn {
 
@@ -168,6 +169,8 @@ void env_step_kernel(const StepParams p)
     float4 Lk[kCoopLp3 ? NLK : 1];
     int lp_nl = 0, lp_fail = 0;
     float ox = 0, oy = 0;
+    bool deferred = false;          // this human's 3-D LP is parked in the queue: env_lp3_kernel integrates it
+    int qidx = 0;
     if (active) {
         if constexpr (MODE == MCN_HUMANS_ORCA) {
             if constexpr (NT > 0) {
@@ -230,14 +233,36 @@ void env_step_kernel(const StepParams p)
                     const float ddx = fpx - rq.x, ddy = fpy - rq.y;
                     dd[NC - 1] = dot2(ddx, ddy, ddx, ddy);
                 }
-                if constexpr (kCoopLp3) {
-                    orca_sort_lp2<NC>(Lnat, dd, (float)attr.y, (float)(goal.x - pos.x), (float)(goal.y - pos.y),
-                                      c.orca_neighbor_dist, c.orca_max_neighbors, ox, oy, lp_fail, lp_nl);
+                int nl_ = 0, fail_ = 0;
+                orca_sort_lp2<NC>(Lnat, dd, (float)attr.y, (float)(goal.x - pos.x), (float)(goal.y - pos.y),
+                                  c.orca_neighbor_dist, c.orca_max_neighbors, ox, oy, fail_, nl_);
+                if (p.lp3_defer) {
+                    // Deferred 3-D LP (lp3_queue.hpp): the few humans whose 2-D LP failed park their problem in the
+                    // queue -- one atomic per wavefront, consecutive slots for its lanes -- and env_lp3_kernel finishes
+                    // and integrates them, one per lane.  Nothing of the 3-D LP runs here.
+                    const bool need = fail_ < nl_;
+                    const unsigned long long m = __ballot(need);
+                    if (m != 0ull) {
+                        const Lp3Queue q = lp3_queue_view(p.out.lp3_queue, (long)p.E * NT);
+                        const int first = __ffsll((long long)m) - 1;
+                        int base = 0;
+                        if (lane == first) base = atomicAdd(q.count, __popcll(m));
+                        base = __shfl(base, first);
+                        if (need) {
+                            deferred = true;
+                            qidx = base + __popcll(m & ((1ull << lane) - 1ull));
+                            q.hdr[qidx] = make_int4((int)a, nl_ | (fail_ << 8), __float_as_int((float)attr.y), 0);
+                            q.res[qidx] = make_float2(ox, oy);
+#pragma unroll
+                            for (int k2 = 0; k2 < NLK; ++k2) q.line[(long)k2 * q.cap + qidx] = Lnat[k2];
+                        }
+                    }
+                } else if constexpr (kCoopLp3) {
+                    lp_fail = fail_; lp_nl = nl_;
 #pragma unroll
                     for (int k2 = 0; k2 < NLK; ++k2) Lk[k2] = Lnat[k2];        // the wavefront finishes them together below
                 } else {
-                    orca_solve_static_lines<NC>(Lnat, dd, (float)attr.y, (float)(goal.x - pos.x), (float)(goal.y - pos.y),
-                                                c.orca_neighbor_dist, c.orca_max_neighbors, ox, oy);
+                    lp3_static<NLK>(Lnat, nl_, fail_, (float)attr.y, ox, oy);
                 }
             } else {
                 GroupCand cand{sAgF, sRadF, make_float4(0, 0, 0, 0), 0.f, gbase, h, N - 1};
@@ -259,8 +284,10 @@ void env_step_kernel(const StepParams p)
     }
 
     if constexpr (kCoopLp3) {
-        CoopLds &coop = reinterpret_cast<CoopLds *>(sRobRadF + BLOCK)[wave];
-        lp3_wave_coop<NLK>(coop, Lk, lp_nl, lp_fail, (float)attr.y, ox, oy);      // every lane of the wavefront
+        if (!p.lp3_defer) {
+            CoopLds &coop = reinterpret_cast<CoopLds *>(sRobRadF + BLOCK)[wave];
+            lp3_wave_coop<NLK>(coop, Lk, lp_nl, lp_fail, (float)attr.y, ox, oy);      // every lane of the wavefront
+        }
         hax = (double)ox; hay = (double)oy;
     }
 
@@ -341,15 +368,21 @@ void env_step_kernel(const StepParams p)
         else                                { rew = 0; dn = 0; inf = MCN_INFO_NOTHING; }
         store_step_rec(p.out.rec + e, rew, dmin, dn, inf, hh_sum);   // 16 + 8 bytes
     }
-    if (active && p.out.human_act)
+    if (active && !deferred && p.out.human_act)
         reinterpret_cast<double2 *>(p.out.human_act)[a] = make_double2(hax, hay);
 
     // ---- integrate / look ahead ----
+    // (a human whose 3-D LP is parked has no velocity yet: it only tells env_lp3_kernel what to write for it --
+    //  1 integrate, 2 look-ahead observation, 0 nothing but the exported action: its env restarts from the pool)
     const double npx = pos.x + hax * dt, npy = pos.y + hay * dt;
     if (!p.update) {
         if (active) {
-            reinterpret_cast<double2 *>(p.out.nobs_pos)[a] = make_double2(npx, npy);
-            reinterpret_cast<double2 *>(p.out.nobs_vel)[a] = make_double2(hax, hay);
+            if (deferred) {
+                lp3_queue_view(p.out.lp3_queue, (long)p.E * N).flag[qidx] = 2;
+            } else {
+                reinterpret_cast<double2 *>(p.out.nobs_pos)[a] = make_double2(npx, npy);
+                reinterpret_cast<double2 *>(p.out.nobs_vel)[a] = make_double2(hax, hay);
+            }
         }
         return;
     }
@@ -367,6 +400,9 @@ void env_step_kernel(const StepParams p)
             reinterpret_cast<double2 *>(p.st.hvel)[a]  = p.roll.pool_hvel
                 ? reinterpret_cast<const double2 *>(p.roll.pool_hvel)[pa] : make_double2(0, 0);
             if (p.st.human_times) p.st.human_times[a] = 0;
+            if (deferred) lp3_queue_view(p.out.lp3_queue, (long)p.E * N).flag[qidx] = 0;
+        } else if (deferred) {
+            lp3_queue_view(p.out.lp3_queue, (long)p.E * N).flag[qidx] = 1;
         } else {
             reinterpret_cast<double2 *>(p.st.hpos)[a] = make_double2(npx, npy);
             reinterpret_cast<double2 *>(p.st.hvel)[a] = make_double2(hax, hay);
@@ -421,6 +457,75 @@ void env_step_kernel(const StepParams p)
     }
 }
 
+// The deferred 3-D LPs of one step (lp3_queue.hpp), one parked problem per lane: every lane of every wavefront works
+// on a human that needs it.  Finishes the solve exactly as the step kernel would have (lp3_static on the same sorted
+// half-planes, same running result) and then does for that human what the step kernel skipped: the exported action,
+// and -- by the flag the step kernel left -- the integration (crowd_sim.py:416-421) or the look-ahead observation
+// (agent.py:63-74).  The last workgroup to finish empties the queue for the next step.
+template <int NL>
+__global__ __launch_bounds__(256) void env_lp3_kernel(const StepParams p)
+{
+    const long cap = (long)p.E * p.N;
+    const Lp3Queue q = lp3_queue_view(p.out.lp3_queue, cap);
+    const int count = __atomic_load_n(q.count, __ATOMIC_RELAXED);
+    const double dt = p.cfg.time_step;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) {
+        const int4 hd = q.hdr[i];
+        const long a = hd.x;
+        const int nl = hd.y & 255, fail = (hd.y >> 8) & 255;
+        const float ms = __int_as_float(hd.z);
+        float4 L[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) L[k] = q.line[(long)k * cap + i];
+        const float2 r0 = q.res[i];
+        float rx = r0.x, ry = r0.y;
+        lp3_static<NL>(L, nl, fail, ms, rx, ry);
+        const double hax = (double)rx, hay = (double)ry;
+        if (p.out.human_act) reinterpret_cast<double2 *>(p.out.human_act)[a] = make_double2(hax, hay);
+        const int flag = q.flag[i];
+        if (flag != 0) {
+            const double2 pos = reinterpret_cast<const double2 *>(p.st.hpos)[a];
+            const double npx = pos.x + hax * dt, npy = pos.y + hay * dt;
+            if (flag == 2) {
+                reinterpret_cast<double2 *>(p.out.nobs_pos)[a] = make_double2(npx, npy);
+                reinterpret_cast<double2 *>(p.out.nobs_vel)[a] = make_double2(hax, hay);
+            } else {
+                reinterpret_cast<double2 *>(p.st.hpos)[a] = make_double2(npx, npy);
+                reinterpret_cast<double2 *>(p.st.hvel)[a] = make_double2(hax, hay);
+                if (p.cfg.track_human_times && p.st.human_times) {
+                    // crowd_sim.py:418-421; the step kernel has already advanced the env's clock to t + dt
+                    const double2 gl = reinterpret_cast<const double2 *>(p.st.hgoal)[a];
+                    if (p.st.human_times[a] == 0 && norm2(npx - gl.x, npy - gl.y) < p.st.hrad[a])
+                        p.st.human_times[a] = p.st.gtime[a / p.N];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // every workgroup has read `count` before it arrives here, so the last one may clear it
+        if (atomicAdd(q.done, 1) == (int)gridDim.x - 1) {
+            __atomic_store_n(q.count, 0, __ATOMIC_RELAXED);
+            __atomic_store_n(q.done, 0, __ATOMIC_RELAXED);
+        }
+    }
+}
+
+static void launch_env_lp3(const StepParams &p, hipStream_t stream)
+{
+    const int nc = p.N - 1 + (p.cfg.robot_visible ? 1 : 0);
+    const long cap = (long)p.E * p.N;
+    long blocks = (cap + 255) / 256;
+    if (blocks > 1024) blocks = 1024;                // grid-stride over the parked problems (a few % of cap)
+#define MCN_LP3_CASE(NL_) case NL_: hipLaunchKernelGGL((env_lp3_kernel<NL_>), dim3((int)blocks), dim3(256), 0, stream, p); break;
+    switch (nc) {
+        MCN_LP3_CASE(1) MCN_LP3_CASE(2) MCN_LP3_CASE(3) MCN_LP3_CASE(4) MCN_LP3_CASE(5) MCN_LP3_CASE(6) MCN_LP3_CASE(7)
+        MCN_LP3_CASE(8) MCN_LP3_CASE(9) MCN_LP3_CASE(10)
+        default: break;
+    }
+#undef MCN_LP3_CASE
+}
+
 static size_t step_smem_bytes(int block, int nl_cap, bool coop = false)
 {
     if (coop)   // + one CoopLds per wavefront (16-byte aligned: every array before it is a multiple of 16 B per lane x 64)
@@ -465,12 +570,21 @@ static void dispatch(const StepParams &p, int blocks, hipStream_t stream)
 bool launch_env_step_quad(const StepParams &p, hipStream_t stream);      // env_step_quad.hip
 bool launch_env_pair(const StepParams &p, hipStream_t stream);           // env_pair.hip
 
-int launch_env_step(const StepParams &p, hipStream_t stream)
+int launch_env_step(const StepParams &p_in, hipStream_t stream)
 {
+    StepParams p = p_in;
+    const int defer_policy = p.lp3_defer;
+    p.lp3_defer = 0;                                  // what the kernels see: 0 / 1
     // <= 4 ORCA neighbours per human: quad-parallel kernel (env_step_quad.hip)
     if (p.quad_max_envs > 0 && p.E <= p.quad_max_envs && launch_env_step_quad(p, stream))
         return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
     const int waves_total = (p.E + p.G - 1) / p.G;
+    // the compile-time-N ORCA kernels park their 3-D LPs when the caller gave them a queue and the batch is large
+    // enough to be throughput-bound (small batches: the cooperative wavefront solve is faster than a second launch)
+    const int nc = p.N - 1 + (p.cfg.robot_visible ? 1 : 0);
+    if (p.out.lp3_queue && p.cfg.human_policy == MCN_HUMANS_ORCA && !p.force_generic && p.N >= 2 && p.N <= 10 &&
+        nc >= 1 && nc <= kMaxLines && (defer_policy > 0 || (defer_policy < 0 && waves_total > 2048)))
+        p.lp3_defer = 1;
     // given velocities, large batch: the streaming form (env_pair.hip); mcn_tuning.pair_stream overrides
     if ((p.pair_stream > 0 || (p.pair_stream < 0 && waves_total > 4096)) && launch_env_pair(p, stream))
         return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
@@ -478,6 +592,7 @@ int launch_env_step(const StepParams &p, hipStream_t stream)
     const bool one_wave = p.step_block > 0 ? p.step_block == 64 : waves_total <= 4096;
     if (one_wave) dispatch<64>(p, waves_total, stream);
     else                     dispatch<256>(p, (waves_total + 3) / 4, stream);
+    if (p.lp3_defer) launch_env_lp3(p, stream);
     return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
 }
 

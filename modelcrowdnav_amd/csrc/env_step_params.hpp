@@ -19,6 +19,7 @@ struct StepParams {
     int debug_noop;      // mcn_tuning.diag_noop, DIAGNOSTIC BUILD ONLY: kernels return at entry (launch-floor measurement)
     int quad_split;      // quad kernel: ORCA and pairwise work on two cooperating wavefronts
     int step_block;      // mcn_tuning.step_block: 64 / 256 lanes per workgroup in the lane-per-human kernels, -1 automatic
+    int lp3_defer;       // mcn_tuning.lp3_defer (-1 automatic); launch_env_step turns it into 0 / 1 for the kernel
     int pair_stream;     // given-velocity step: streaming kernel of env_pair.hip (-1 automatic, 0 never, 1 where it applies)
 };
 

@@ -7,6 +7,7 @@
 #include "../../include/mcn.h"
 
 #include "env_step_params.hpp"
+#include "lp3_queue.hpp"
 
 namespace mcn {
 int launch_env_step(const StepParams &p, hipStream_t stream);
@@ -54,6 +55,7 @@ static mcn_tuning tuning_from_env()
     t.rollout_split = env_or("MCN_ROLLOUT_SPLIT", -1);
     t.step_block = env_or("MCN_STEP_BLOCK", -1);
     t.pair_stream = env_or("MCN_PAIR_STREAM", -1);
+    t.lp3_defer = env_or("MCN_LP3_DEFER", -1);
     return t;
 }
 static const mcn_tuning &tuning()
@@ -102,6 +104,7 @@ static int fill_step_params(mcn::StepParams &p, const mcn_env_cfg *cfg, const mc
     p.force_generic = tu.force_generic > 0 ? 1 : 0;
     p.pair_stream = tu.pair_stream;
     p.step_block = tu.step_block;
+    p.lp3_defer = tu.lp3_defer;
 #ifdef MCN_DIAG
     p.debug_noop = tu.diag_noop;
 #endif
@@ -126,6 +129,7 @@ int mcn_set_tuning(const mcn_tuning *t)
     if (t->quad_split > 1 || t->rollout_fused > 1 || t->rollout_split > 1 || t->pair_stream > 1 || t->force_generic < 0 || t->force_generic > 1) return MCN_EINVAL;
     if (t->quad_max_envs < -1 || t->quad_split < -1 || t->rollout_fused < -1 || t->rollout_split < -1 || t->pair_stream < -1) return MCN_EINVAL;
     if (t->step_block != -1 && t->step_block != 64 && t->step_block != 256) return MCN_EINVAL;
+    if (t->lp3_defer < -1 || t->lp3_defer > 1) return MCN_EINVAL;
 #ifndef MCN_DIAG
     if (t->diag_noop) return MCN_EINVAL;          // kernels that do nothing exist in the diagnostic build only
 #endif
@@ -139,6 +143,12 @@ int mcn_get_tuning(mcn_tuning *t)
     if (!t) return MCN_EINVAL;
     *t = tuning();
     return MCN_OK;
+}
+
+int64_t mcn_env_lp3_queue_bytes(int32_t E, int32_t N)
+{
+    if (E <= 0 || N < 2 || N > 10) return 0;          // the compile-time-N ORCA kernels (env_step.hip)
+    return mcn::lp3_queue_bytes((long)E * N, N < MCN_MAX_LINES ? N : MCN_MAX_LINES);
 }
 
 int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *actions,

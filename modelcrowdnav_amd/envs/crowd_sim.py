@@ -131,8 +131,13 @@ class VecCrowdSim(object):
         self._st = _hip.EnvState(*[_hip.ptr(t) for t in (self.hpos, self.hvel, self.hgoal, self.hrad, self.hvpref,
                                                          self.rpos, self.rvel, self.rgoal, self.rrad, self.rvpref,
                                                          self.rtheta, self.gtime, self.human_times)])
-        self._out = _hip.EnvOut(*[_hip.ptr(t) for t in (self.step_rec, self.human_act, self.nobs_pos, self.nobs_vel)])
-        self._out_lean = _hip.EnvOut(*[_hip.ptr(t) for t in (self.step_rec, None, self.nobs_pos, self.nobs_vel)])
+        # work queue of the deferred 3-D LP (mcn.h: mcn_env_out.lp3_queue): zero-filled once, then the kernels' own
+        nq = int(_hip.lib.mcn_env_lp3_queue_bytes(E, N))
+        self.lp3_queue = torch.zeros(nq, dtype=torch.uint8, device=dev) if nq > 0 else None
+        self._out = _hip.EnvOut(*[_hip.ptr(t) for t in (self.step_rec, self.human_act, self.nobs_pos, self.nobs_vel,
+                                                        self.lp3_queue)])
+        self._out_lean = _hip.EnvOut(*[_hip.ptr(t) for t in (self.step_rec, None, self.nobs_pos, self.nobs_vel,
+                                                             self.lp3_queue)])
 
     def _cfg_struct(self, human_policy=None):
         hp = {"orca": _hip.HUMANS_ORCA, "linear": _hip.HUMANS_LINEAR, "given": _hip.HUMANS_GIVEN}[

@@ -28,7 +28,8 @@ def test_struct_sizes_match_header():
     from modelcrowdnav_amd import _hip
     assert ctypes.sizeof(_hip.EnvCfg) == 7 * 8 + 2 * 4 + 6 * 4
     assert ctypes.sizeof(_hip.EnvState) == 14 * 8 and _hip.EnvState.hcount.offset == 13 * 8
-    assert ctypes.sizeof(_hip.EnvOut) == 4 * 8
+    assert ctypes.sizeof(_hip.EnvOut) == 5 * 8 and _hip.EnvOut.lp3_queue.offset == 32
+    assert ctypes.sizeof(_hip.Tuning) == 9 * 4
     assert ctypes.sizeof(_hip.StepRec) == 24 and _hip.StepRec.done.offset == 16 and _hip.StepRec.hh_count.offset == 20
     assert ctypes.sizeof(_hip.RollRec) == 32 and _hip.RollRec.fin_count.offset == 12
     assert _hip.RollRec.danger_dist_sum.offset == 24

@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--visible", action="store_true")
     ap.add_argument("--no-hh", action="store_true", help="no human-human overlap count (ModelCrowdSim.step does not count)")
     ap.add_argument("--pair-stream", type=int, default=-1, help="mcn_tuning.pair_stream")
+    ap.add_argument("--lp3-defer", type=int, default=-1, help="mcn_tuning.lp3_defer")
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--sarl", action="store_true")
     ap.add_argument("--rollout", type=int, default=0, help="time mcn_env_rollout with this many steps per launch")
@@ -77,6 +78,9 @@ def main():
         if a.pair_stream >= 0:
             from modelcrowdnav_amd import _hip
             _hip.set_tuning(pair_stream=a.pair_stream)
+        if a.lp3_defer >= 0:
+            from modelcrowdnav_amd import _hip
+            _hip.set_tuning(lp3_defer=a.lp3_defer)
         acts = bench.make_actions(16, E, E, 0, dev)
         gv = torch.rand(E, N, 2, dtype=torch.float64, device=dev) - 0.5
         for mode in a.modes.split(","):

@@ -430,12 +430,26 @@ def extra_configs(device):
     return out
 
 
+def sarl_mfma_per_tile(N):
+    """v_mfma_f32_16x16x4_f32 instructions sarl_value_kernel issues per 16-pair tile (csrc/sarl_value.hip: output tiles
+    x the k-steps of the input tiles that carry anything): per human mlp1 40 + 266, attention 175 + 175 + 25, mlp2's
+    first layer 175; per pair the global half of attention.0 175, mlp2's linear last layer 100 (applied once to the
+    attention-weighted sum), mlp3 150 + 266 + 175 + 25."""
+    return N * (40 + 266 + 175 + 175 + 25 + 175) + (175 + 100 + 150 + 266 + 175 + 25)
+
+
 def _sarl_roofline(E, N, ms_net):
-    flop = 81 * (N * 124100 + 67000) * E
+    """`achieved` / `frac` count the FLOP the kernel EXECUTES (MFMAs issued x 2 048, tile padding included); the
+    reference formulation's count (81 x (N x 124 100 + 67 000) per env-step) is reported beside it."""
+    reference = 81 * (N * 124100 + 67000) * E
+    tiles = (E * 81 + 15) // 16
+    executed = tiles * sarl_mfma_per_tile(N) * 2048
     tr, src = net_traffic("sarl_value_kernel", E, N)
-    return {"bound": "mfma", "kernel": "mcn::sarl_value_kernel", "achieved": round(flop / ms_net / 1e9, 2),
-            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop / ms_net / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
-            "traffic": tr, "traffic_source": src, "algorithmic_flop_per_launch": flop,
+    return {"bound": "mfma", "kernel": "mcn::sarl_value_kernel", "achieved": round(executed / ms_net / 1e9, 2),
+            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(executed / ms_net / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
+            "traffic": tr, "traffic_source": src, "executed_flop_per_launch": executed,
+            "reference_flop_per_launch": reference, "reference_flop_rate": round(reference / ms_net / 1e9, 2),
+            "reference_flop_rate_over_peak": round(reference / ms_net / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
             "avg_launch_us": round(ms_net * 1e3, 1), "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}
 
 

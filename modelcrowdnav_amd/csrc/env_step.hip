@@ -243,27 +243,33 @@ void env_step_kernel(const StepParams p)
                     const bool need = fail_ < nl_;
                     const unsigned long long m = __ballot(need);
                     if (m != 0ull) {
-                        const Lp3Queue q = lp3_queue_view(p.out.lp3_queue, (long)p.E * NT);
+                        const Lp3Queue q = lp3_queue_view(p.out.lp3_queue, p.E, NT);
+                        const int sub = (int)((blockIdx.x * (BLOCK / 64) + wave) & (kLp3Queues - 1));
                         const int first = __ffsll((long long)m) - 1;
                         int base = 0;
-                        if (lane == first) base = atomicAdd(q.count, __popcll(m));
+                        if (lane == first) base = atomicAdd(q.count(sub), __popcll(m));
                         base = __shfl(base, first);
                         if (need) {
                             deferred = true;
-                            qidx = base + __popcll(m & ((1ull << lane) - 1ull));
+                            qidx = (int)(sub * q.subcap) + base + __popcll(m & ((1ull << lane) - 1ull));
                             q.hdr[qidx] = make_int4((int)a, nl_ | (fail_ << 8), __float_as_int((float)attr.y), 0);
                             q.res[qidx] = make_float2(ox, oy);
 #pragma unroll
                             for (int k2 = 0; k2 < NLK; ++k2) q.line[(long)k2 * q.cap + qidx] = Lnat[k2];
                         }
                     }
-                } else if constexpr (kCoopLp3) {
+                }
+#ifdef MCN_LP3_ONLY_DEFER          // experiment: no in-kernel 3-D LP at all (register / occupancy study)
+                else {}
+#else
+                else if constexpr (kCoopLp3) {
                     lp_fail = fail_; lp_nl = nl_;
 #pragma unroll
                     for (int k2 = 0; k2 < NLK; ++k2) Lk[k2] = Lnat[k2];        // the wavefront finishes them together below
                 } else {
                     lp3_static<NLK>(Lnat, nl_, fail_, (float)attr.y, ox, oy);
                 }
+#endif
             } else {
                 GroupCand cand{sAgF, sRadF, make_float4(0, 0, 0, 0), 0.f, gbase, h, N - 1};
                 int ncand = N - 1;
@@ -284,10 +290,12 @@ void env_step_kernel(const StepParams p)
     }
 
     if constexpr (kCoopLp3) {
+#ifndef MCN_LP3_ONLY_DEFER
         if (!p.lp3_defer) {
             CoopLds &coop = reinterpret_cast<CoopLds *>(sRobRadF + BLOCK)[wave];
             lp3_wave_coop<NLK>(coop, Lk, lp_nl, lp_fail, (float)attr.y, ox, oy);      // every lane of the wavefront
         }
+#endif
         hax = (double)ox; hay = (double)oy;
     }
 
@@ -378,7 +386,7 @@ void env_step_kernel(const StepParams p)
     if (!p.update) {
         if (active) {
             if (deferred) {
-                lp3_queue_view(p.out.lp3_queue, (long)p.E * N).flag[qidx] = 2;
+                lp3_queue_view(p.out.lp3_queue, p.E, N).flag[qidx] = 2;
             } else {
                 reinterpret_cast<double2 *>(p.out.nobs_pos)[a] = make_double2(npx, npy);
                 reinterpret_cast<double2 *>(p.out.nobs_vel)[a] = make_double2(hax, hay);
@@ -400,9 +408,9 @@ void env_step_kernel(const StepParams p)
             reinterpret_cast<double2 *>(p.st.hvel)[a]  = p.roll.pool_hvel
                 ? reinterpret_cast<const double2 *>(p.roll.pool_hvel)[pa] : make_double2(0, 0);
             if (p.st.human_times) p.st.human_times[a] = 0;
-            if (deferred) lp3_queue_view(p.out.lp3_queue, (long)p.E * N).flag[qidx] = 0;
+            if (deferred) lp3_queue_view(p.out.lp3_queue, p.E, N).flag[qidx] = 0;
         } else if (deferred) {
-            lp3_queue_view(p.out.lp3_queue, (long)p.E * N).flag[qidx] = 1;
+            lp3_queue_view(p.out.lp3_queue, p.E, N).flag[qidx] = 1;
         } else {
             reinterpret_cast<double2 *>(p.st.hpos)[a] = make_double2(npx, npy);
             reinterpret_cast<double2 *>(p.st.hvel)[a] = make_double2(hax, hay);
@@ -457,67 +465,108 @@ void env_step_kernel(const StepParams p)
     }
 }
 
-// The deferred 3-D LPs of one step (lp3_queue.hpp), one parked problem per lane: every lane of every wavefront works
-// on a human that needs it.  Finishes the solve exactly as the step kernel would have (lp3_static on the same sorted
-// half-planes, same running result) and then does for that human what the step kernel skipped: the exported action,
-// and -- by the flag the step kernel left -- the integration (crowd_sim.py:416-421) or the look-ahead observation
-// (agent.py:63-74).  The last workgroup to finish empties the queue for the next step.
+// The deferred 3-D LPs of one step (lp3_queue.hpp).  Finishes each parked solve exactly as the step kernel would have
+// (same sorted half-planes, same running result) and then does for that human what the step kernel skipped: the
+// exported action, and -- by the flag the step kernel left -- the integration (crowd_sim.py:416-421) or the look-ahead
+// observation (agent.py:63-74).  Workgroup b serves sub-queue b % 256.  Two forms (A/B switch MCN_LP3_KB_COOP):
+//   0  one problem per lane, the register-resident unrolled solver (lp3_static): every lane busy, but a wavefront of
+//      64 different problems walks the union of all their paths through the O(n^3) code;
+//   1  eight problems per wavefront, eight lanes each (lp3_wave_coop, orca_coop.hpp): a ~4x shorter dependent chain,
+//      which is what bounds this launch -- it holds a few % of the step's humans and runs far below the chip's width.
+// The last workgroup to finish empties the queue for the next step.
+#ifndef MCN_LP3_KB_COOP
+#define MCN_LP3_KB_COOP 1
+#endif
 template <int NL>
-__global__ __launch_bounds__(256) void env_lp3_kernel(const StepParams p)
+__global__ __launch_bounds__(256) void env_lp3_kernel(const StepParams p, const int per_queue)
 {
-    const long cap = (long)p.E * p.N;
-    const Lp3Queue q = lp3_queue_view(p.out.lp3_queue, cap);
-    const int count = __atomic_load_n(q.count, __ATOMIC_RELAXED);
+    const Lp3Queue q = lp3_queue_view(p.out.lp3_queue, p.E, p.N);
+    const int sub = blockIdx.x & (kLp3Queues - 1), rep = blockIdx.x / kLp3Queues;
+    const int count = __atomic_load_n(q.count(sub), __ATOMIC_RELAXED);
+    const long qbase = (long)sub * q.subcap;
     const double dt = p.cfg.time_step;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) {
-        const int4 hd = q.hdr[i];
-        const long a = hd.x;
-        const int nl = hd.y & 255, fail = (hd.y >> 8) & 255;
-        const float ms = __int_as_float(hd.z);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#if MCN_LP3_KB_COOP
+    __shared__ CoopLds s_coop[4];
+    constexpr int kPerWave = kCoopSlots;                          // problems a wavefront takes per pass
+    const bool holder = lane < kPerWave;
+    for (int i0 = (rep * 4 + wave) * kPerWave; i0 < count; i0 += per_queue * 4 * kPerWave) {
+        const int i = i0 + lane;
+        const bool mine = holder && i < count;
+        const long s = qbase + (mine ? i : 0);
+#else
+    constexpr bool holder = true;
+    for (int i0 = rep * 256; i0 < count; i0 += per_queue * 256) {
+        const int i = i0 + threadIdx.x;
+        const bool mine = i < count;
+        const long s = qbase + (mine ? i : 0);
+#endif
+        int4 hd = make_int4(0, 0, 0, 0);
         float4 L[NL];
+        float2 r0 = make_float2(0, 0);
+        if (mine) {
+            hd = q.hdr[s];
 #pragma unroll
-        for (int k = 0; k < NL; ++k) L[k] = q.line[(long)k * cap + i];
-        const float2 r0 = q.res[i];
+            for (int k = 0; k < NL; ++k) L[k] = q.line[(long)k * q.cap + s];
+            r0 = q.res[s];
+        } else {
+#pragma unroll
+            for (int k = 0; k < NL; ++k) L[k] = make_float4(0, 0, 1, 0);
+        }
+        const long a = hd.x;
+        const int nl = hd.y & 255, fail = mine ? ((hd.y >> 8) & 255) : 0;
+        const float ms = __int_as_float(hd.z);
         float rx = r0.x, ry = r0.y;
-        lp3_static<NL>(L, nl, fail, ms, rx, ry);
-        const double hax = (double)rx, hay = (double)ry;
-        if (p.out.human_act) reinterpret_cast<double2 *>(p.out.human_act)[a] = make_double2(hax, hay);
-        const int flag = q.flag[i];
-        if (flag != 0) {
-            const double2 pos = reinterpret_cast<const double2 *>(p.st.hpos)[a];
-            const double npx = pos.x + hax * dt, npy = pos.y + hay * dt;
-            if (flag == 2) {
-                reinterpret_cast<double2 *>(p.out.nobs_pos)[a] = make_double2(npx, npy);
-                reinterpret_cast<double2 *>(p.out.nobs_vel)[a] = make_double2(hax, hay);
-            } else {
-                reinterpret_cast<double2 *>(p.st.hpos)[a] = make_double2(npx, npy);
-                reinterpret_cast<double2 *>(p.st.hvel)[a] = make_double2(hax, hay);
-                if (p.cfg.track_human_times && p.st.human_times) {
-                    // crowd_sim.py:418-421; the step kernel has already advanced the env's clock to t + dt
-                    const double2 gl = reinterpret_cast<const double2 *>(p.st.hgoal)[a];
-                    if (p.st.human_times[a] == 0 && norm2(npx - gl.x, npy - gl.y) < p.st.hrad[a])
-                        p.st.human_times[a] = p.st.gtime[a / p.N];
+#if MCN_LP3_KB_COOP
+        lp3_wave_coop<NL>(s_coop[wave], L, mine ? nl : 0, fail, ms, rx, ry);       // every lane of the wavefront
+#else
+        if (mine) lp3_static<NL>(L, nl, fail, ms, rx, ry);
+#endif
+        if (mine) {
+            const double hax = (double)rx, hay = (double)ry;
+            if (p.out.human_act) reinterpret_cast<double2 *>(p.out.human_act)[a] = make_double2(hax, hay);
+            const int flag = q.flag[s];
+            if (flag != 0) {
+                const double2 pos = reinterpret_cast<const double2 *>(p.st.hpos)[a];
+                const double npx = pos.x + hax * dt, npy = pos.y + hay * dt;
+                if (flag == 2) {
+                    reinterpret_cast<double2 *>(p.out.nobs_pos)[a] = make_double2(npx, npy);
+                    reinterpret_cast<double2 *>(p.out.nobs_vel)[a] = make_double2(hax, hay);
+                } else {
+                    reinterpret_cast<double2 *>(p.st.hpos)[a] = make_double2(npx, npy);
+                    reinterpret_cast<double2 *>(p.st.hvel)[a] = make_double2(hax, hay);
+                    if (p.cfg.track_human_times && p.st.human_times) {
+                        // crowd_sim.py:418-421; the step kernel has already advanced the env's clock to t + dt
+                        const double2 gl = reinterpret_cast<const double2 *>(p.st.hgoal)[a];
+                        if (p.st.human_times[a] == 0 && norm2(npx - gl.x, npy - gl.y) < p.st.hrad[a])
+                            p.st.human_times[a] = p.st.gtime[a / p.N];
+                    }
                 }
             }
         }
     }
+    (void)holder;
+    // every workgroup has read its sub-queue's count before it arrives here, so the last one may clear them all
+    __shared__ int s_last;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        // every workgroup has read `count` before it arrives here, so the last one may clear it
-        if (atomicAdd(q.done, 1) == (int)gridDim.x - 1) {
-            __atomic_store_n(q.count, 0, __ATOMIC_RELAXED);
-            __atomic_store_n(q.done, 0, __ATOMIC_RELAXED);
-        }
+    if (threadIdx.x == 0) s_last = (atomicAdd(q.done(), 1) == (int)gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (s_last) {
+        static_assert(kLp3Queues == 256, "one thread per sub-queue counter");
+        __atomic_store_n(q.count(threadIdx.x), 0, __ATOMIC_RELAXED);
+        if (threadIdx.x == 0) __atomic_store_n(q.done(), 0, __ATOMIC_RELAXED);
     }
 }
 
 static void launch_env_lp3(const StepParams &p, hipStream_t stream)
 {
     const int nc = p.N - 1 + (p.cfg.robot_visible ? 1 : 0);
-    const long cap = (long)p.E * p.N;
-    long blocks = (cap + 255) / 256;
-    if (blocks > 1024) blocks = 1024;                // grid-stride over the parked problems (a few % of cap)
-#define MCN_LP3_CASE(NL_) case NL_: hipLaunchKernelGGL((env_lp3_kernel<NL_>), dim3((int)blocks), dim3(256), 0, stream, p); break;
+    // workgroups per sub-queue: enough that the expected few % of a sub-queue's slots are taken in one or two passes
+    const long subcap = lp3_subcap(p.E, p.N);
+    long per_queue = subcap / 512;
+    per_queue = per_queue < 1 ? 1 : (per_queue > 8 ? 8 : per_queue);
+    const int blocks = (int)(kLp3Queues * per_queue);
+#define MCN_LP3_CASE(NL_) case NL_: hipLaunchKernelGGL((env_lp3_kernel<NL_>), dim3(blocks), dim3(256), 0, stream, p, (int)per_queue); break;
     switch (nc) {
         MCN_LP3_CASE(1) MCN_LP3_CASE(2) MCN_LP3_CASE(3) MCN_LP3_CASE(4) MCN_LP3_CASE(5) MCN_LP3_CASE(6) MCN_LP3_CASE(7)
         MCN_LP3_CASE(8) MCN_LP3_CASE(9) MCN_LP3_CASE(10)

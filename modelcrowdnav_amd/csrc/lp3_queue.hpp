@@ -4,55 +4,69 @@
 // it, but a wavefront holds 60 of them, so 70-85 % of the wavefronts run its unrolled O(n^3) code for one or two
 // active lanes (a third of the N = 5 kernel's instructions, two thirds of the N = 10 kernel's).  With a queue the
 // step kernel stops after the 2-D LP: a human whose 2-D LP failed parks its sorted half-planes, the line count, the
-// first failing line and the running result here (one wave-aggregated atomic per wavefront) and leaves its own
-// integration to env_lp3_kernel, a second launch that solves the parked problems one per lane -- every lane busy --
-// and writes those humans' velocities / positions.  Same arithmetic (lp3_static on the same sorted lines), so the
-// same bits.
+// first failing line and the running result here and leaves its own integration to env_lp3_kernel, a second launch
+// that finishes the parked problems densely and writes those humans' velocities / positions.  Same arithmetic on the
+// same sorted lines, so the same bits.
 //
-// Layout (cap = E * N entries, SoA so that a wavefront's consecutive entries are consecutive in memory):
-//   [0]  int count      entries of the running step (reset to 0 by env_lp3_kernel's last workgroup)
-//   [4]  int done       workgroups of env_lp3_kernel that have finished
-//   [64] int4   hdr [cap]   (human index e * N + h, nl | fail << 8, max speed bits, 0)
-//        float2 res [cap]   running result when the 2-D LP failed
-//        int    flag[cap]   1: integrate the human (update, env not restarted)  2: write the look-ahead observation
-//        float4 line[NL][cap]
+// kLp3Queues sub-queues, one counter each, 256 B apart: a wavefront appends with ONE atomic (its lanes take
+// consecutive slots) to the sub-queue its global wavefront index selects.  One counter for the whole grid would
+// serialise tens of thousands of device-scope atomics on one address (they execute memory-side on this multi-XCD
+// part, ~8 ns apiece: measured 2^20 envs x 5: +95 us); 256 counters spread them over the channels.
+//
+// Layout (subcap entries per sub-queue, SoA inside a sub-queue so consecutive entries are consecutive in memory):
+//   [q * 256]     int count[q]         entries of the running step (reset by env_lp3_kernel's last workgroup)
+//   [65536]       int done             workgroups of env_lp3_kernel that have finished
+//   [66560]       int4   hdr [cap]     (human index e * N + h, nl | fail << 8, max speed bits, 0), cap = 256 * subcap
+//                 float2 res [cap]     running result when the 2-D LP failed
+//                 int    flag[cap]     1: integrate the human (update, env not restarted)  2: look-ahead observation
+//                 float4 line[NL][cap]
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace mcn {
 
+constexpr int kLp3Queues = 256;
+constexpr long kLp3Header = 66560;
+
 struct Lp3Queue {
-    int *count, *done;
+    char *base;
     int4 *hdr;
     float2 *res;
     int *flag;
     float4 *line;
-    long cap;
+    long subcap, cap;
+    __host__ __device__ __forceinline__ int *count(int q) const { return reinterpret_cast<int *>(base + (long)q * 256); }
+    __host__ __device__ __forceinline__ int *done() const { return reinterpret_cast<int *>(base + 65536); }
 };
 
-__host__ __device__ __forceinline__ long lp3_queue_lines_offset(long cap)
+// entries one sub-queue must hold in the worst case: the wavefronts mapped to it (every 256th of the grid, up to three
+// idle ones from rounding the grid to workgroups of four) x 64 lanes
+__host__ __device__ __forceinline__ long lp3_subcap(long E, int N)
 {
-    return (64 + cap * 28 + 15) & ~15L;
+    const long waves = (E + (64 / N) - 1) / (64 / N) + 3;
+    return (waves + kLp3Queues - 1) / kLp3Queues * 64;
 }
 
-__host__ __device__ __forceinline__ Lp3Queue lp3_queue_view(void *base, long cap)
+__host__ __device__ __forceinline__ long lp3_lines_offset(long cap) { return (kLp3Header + cap * 28 + 15) & ~15L; }
+
+__host__ __device__ __forceinline__ Lp3Queue lp3_queue_view(void *base, long E, int N)
 {
-    char *b = reinterpret_cast<char *>(base);
     Lp3Queue q;
-    q.count = reinterpret_cast<int *>(b);
-    q.done = reinterpret_cast<int *>(b + 4);
-    q.hdr = reinterpret_cast<int4 *>(b + 64);
-    q.res = reinterpret_cast<float2 *>(b + 64 + cap * 16);
-    q.flag = reinterpret_cast<int *>(b + 64 + cap * 24);
-    q.line = reinterpret_cast<float4 *>(b + lp3_queue_lines_offset(cap));
-    q.cap = cap;
+    q.base = reinterpret_cast<char *>(base);
+    q.subcap = lp3_subcap(E, N);
+    q.cap = q.subcap * kLp3Queues;
+    q.hdr = reinterpret_cast<int4 *>(q.base + kLp3Header);
+    q.res = reinterpret_cast<float2 *>(q.base + kLp3Header + q.cap * 16);
+    q.flag = reinterpret_cast<int *>(q.base + kLp3Header + q.cap * 24);
+    q.line = reinterpret_cast<float4 *>(q.base + lp3_lines_offset(q.cap));
     return q;
 }
 
-__host__ __device__ __forceinline__ long lp3_queue_bytes(long cap, int nl)
+__host__ __device__ __forceinline__ long lp3_queue_bytes(long E, int N, int nl)
 {
-    return lp3_queue_lines_offset(cap) + cap * 16 * nl;
+    const long cap = lp3_subcap(E, N) * kLp3Queues;
+    return lp3_lines_offset(cap) + cap * 16 * nl;
 }
 
 }  // namespace mcn

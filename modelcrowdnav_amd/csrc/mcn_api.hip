@@ -148,7 +148,7 @@ int mcn_get_tuning(mcn_tuning *t)
 int64_t mcn_env_lp3_queue_bytes(int32_t E, int32_t N)
 {
     if (E <= 0 || N < 2 || N > 10) return 0;          // the compile-time-N ORCA kernels (env_step.hip)
-    return mcn::lp3_queue_bytes((long)E * N, N < MCN_MAX_LINES ? N : MCN_MAX_LINES);
+    return mcn::lp3_queue_bytes(E, N, N < MCN_MAX_LINES ? N : MCN_MAX_LINES);
 }
 
 int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *actions,

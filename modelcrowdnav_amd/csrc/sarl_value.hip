@@ -27,8 +27,9 @@
 //                      the batch -- it lives in the 256 MB Infinity Cache between the two passes instead of making a
 //                      round trip through HBM (0.74 / 1.49 GB per look-ahead when it was indexed by tile).
 //   pass 2, per human: attention (200->100->100->1) with the global half folded into the accumulator
-//                      init, exp, mlp2 (100->100->50), pooled += e * mlp2_out.
-//   tail:              mlp3 (56->150->100->100->1), value, store.
+//                      init, exp, mlp2's first layer (100->100), acc += e * relu(.).
+//   tail:              mlp2's second, linear layer (100->50) once on acc / sum(e); mlp3 (56->150->100->100->1),
+//                      value, store.
 //
 // Arithmetic: float32 MFMA is an exact k-ordered fmaf chain (no TF32), so values match the
 // reference's float32 network to summation-order noise (~1e-6); rewards are float64 in the
@@ -211,9 +212,13 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
     dense_staged<T100, T100, false, false, 1>(gsum, nullptr, gat, p.f.w_atg, p.f.b_ata, S, lane);
 
     // ---- pass 2: attention score, mlp2, pooling ----
-    f32x4 pooled[T50];
+    // mlp2's last layer is linear (sarl.py:31, cadrl.py:11-19: no ReLU after the last Linear) and the attention
+    // weights sum to one, so  sum_i w_i (W r_i + b) = W (sum_i w_i r_i) + b  with r_i = relu(mlp2.0(h_i)): the
+    // weighted sum is taken over the 100-wide hidden activations and mlp2.2 runs ONCE per pair instead of once
+    // per human (100 MFMAs per human fewer; same value to float32 summation-order noise, ~1e-7).
+    f32x4 racc[T100];
 #pragma unroll
-    for (int t = 0; t < T50; ++t) pooled[t] = (f32x4){0, 0, 0, 0};
+    for (int t = 0; t < T100; ++t) racc[t] = (f32x4){0, 0, 0, 0};
     float denom = 0.0f;
     for (int i = 0; i < N; ++i) {
         int tid_i = tid;
@@ -238,20 +243,25 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
         denom += es;
         f32x4 m1[T100];
         dense_staged<T100, T100, true, false, 1>(h2, nullptr, m1, p.f.w_m2a, p.f.b_m2a, S, lane);
-        f32x4 m2[T50];
-        dense_staged<T100, T50, false, false, 1>(m1, nullptr, m2, p.f.w_m2b, p.f.b_m2b, S, lane);
 #pragma unroll
-        for (int t = 0; t < T50; ++t)
+        for (int t = 0; t < T100; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pooled[t][r] = i < ne ? pooled[t][r] + es * m2[t][r] : pooled[t][r];
+            for (int r = 0; r < 4; ++r) racc[t][r] = i < ne ? racc[t][r] + es * m1[t][r] : racc[t][r];
     }
 
     // ---- tail: mlp3 on [self(6), pooled(50)] ----
     f32x4 jin[T56];
+    {
+        // weights = exp(s) (s != 0) / sum (sarl.py:52-53): normalise the accumulated hidden activations, then mlp2.2
 #pragma unroll
-    for (int t = 0; t < T50; ++t)
+        for (int t = 0; t < T100; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) jin[t][r] = pooled[t][r] / denom;
+            for (int r = 0; r < 4; ++r) racc[t][r] = racc[t][r] / denom;
+        f32x4 pooled[T50];
+        dense_staged<T100, T50, false, false, 1>(racc, nullptr, pooled, p.f.w_m2b, p.f.b_m2b, S, lane);
+#pragma unroll
+        for (int t = 0; t < T50; ++t) jin[t] = pooled[t];
+    }
     {
         // the 6 self features, packed "q first": feature j sits in register j/4 of lane group j%4 (two k-steps)
         const float s0 = q == 0 ? dg : (q == 1 ? svpref : (q == 2 ? f_theta : srad));

@@ -344,7 +344,7 @@ typedef struct mcn_tuning {
     int32_t diag_noop;       /* DIAGNOSTIC build only (make stamp): env kernels return at entry; MCN_EINVAL otherwise */
     int32_t pair_stream;     /* given-velocity step: streaming kernel (env_pair.hip) 1 wherever it applies / 0 never */
     int32_t lp3_defer;       /* lane-per-human ORCA kernels with mcn_env_out.lp3_queue set: park the 3-D LPs for a second,
-                              * dense launch (1) or solve them in the step kernel (0); -1: defer above 2048 wavefronts */
+                              * dense launch (1) or solve them in the step kernel (0); -1: defer from 8 ORCA neighbours and 16 384 wavefronts */
 } mcn_tuning;
 
 /* NULL restores the initial values.  Returns MCN_EINVAL for out-of-range fields.  The settings are one unsynchronised

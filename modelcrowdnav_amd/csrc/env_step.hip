@@ -258,18 +258,13 @@ void env_step_kernel(const StepParams p)
                             for (int k2 = 0; k2 < NLK; ++k2) q.line[(long)k2 * q.cap + qidx] = Lnat[k2];
                         }
                     }
-                }
-#ifdef MCN_LP3_ONLY_DEFER          // experiment: no in-kernel 3-D LP at all (register / occupancy study)
-                else {}
-#else
-                else if constexpr (kCoopLp3) {
+                } else if constexpr (kCoopLp3) {
                     lp_fail = fail_; lp_nl = nl_;
 #pragma unroll
                     for (int k2 = 0; k2 < NLK; ++k2) Lk[k2] = Lnat[k2];        // the wavefront finishes them together below
                 } else {
                     lp3_static<NLK>(Lnat, nl_, fail_, (float)attr.y, ox, oy);
                 }
-#endif
             } else {
                 GroupCand cand{sAgF, sRadF, make_float4(0, 0, 0, 0), 0.f, gbase, h, N - 1};
                 int ncand = N - 1;
@@ -290,12 +285,10 @@ void env_step_kernel(const StepParams p)
     }
 
     if constexpr (kCoopLp3) {
-#ifndef MCN_LP3_ONLY_DEFER
         if (!p.lp3_defer) {
             CoopLds &coop = reinterpret_cast<CoopLds *>(sRobRadF + BLOCK)[wave];
             lp3_wave_coop<NLK>(coop, Lk, lp_nl, lp_fail, (float)attr.y, ox, oy);      // every lane of the wavefront
         }
-#endif
         hax = (double)ox; hay = (double)oy;
     }
 
@@ -628,11 +621,15 @@ int launch_env_step(const StepParams &p_in, hipStream_t stream)
     if (p.quad_max_envs > 0 && p.E <= p.quad_max_envs && launch_env_step_quad(p, stream))
         return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
     const int waves_total = (p.E + p.G - 1) / p.G;
-    // the compile-time-N ORCA kernels park their 3-D LPs when the caller gave them a queue and the batch is large
-    // enough to be throughput-bound (small batches: the cooperative wavefront solve is faster than a second launch)
+    // The compile-time-N ORCA kernels can park their 3-D LPs when the caller gave them a queue.  Measured on MI355X
+    // (round 3, circle crossing with pool restarts; step kernel alone / + the finish kernel vs solving in place):
+    // 10 humans 2^18 envs 344 -> 249 + 40 us, 32 768 envs 65 -> 65, 4096 envs 27 -> 31; 7 humans 2^18 envs 110 -> 122;
+    // 5 humans 2^20 envs 207 -> 205 + 20.  Only 0.9 / 1.8 / 3.7 % of the humans need the 3-D LP at 5 / 7 / 10 humans
+    // and the in-place code already skips every block no lane of the wavefront needs, so deferral pays only for the
+    // largest crowds in throughput-bound batches: automatic from 8 neighbours and 16 384 wavefronts.
     const int nc = p.N - 1 + (p.cfg.robot_visible ? 1 : 0);
     if (p.out.lp3_queue && p.cfg.human_policy == MCN_HUMANS_ORCA && !p.force_generic && p.N >= 2 && p.N <= 10 &&
-        nc >= 1 && nc <= kMaxLines && (defer_policy > 0 || (defer_policy < 0 && waves_total > 2048)))
+        nc >= 1 && nc <= kMaxLines && (defer_policy > 0 || (defer_policy < 0 && nc >= 8 && waves_total >= 16384)))
         p.lp3_defer = 1;
     // given velocities, large batch: the streaming form (env_pair.hip); mcn_tuning.pair_stream overrides
     if ((p.pair_stream > 0 || (p.pair_stream < 0 && waves_total > 4096)) && launch_env_pair(p, stream))

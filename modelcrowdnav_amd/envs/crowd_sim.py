@@ -132,8 +132,12 @@ class VecCrowdSim(object):
                                                          self.rpos, self.rvel, self.rgoal, self.rrad, self.rvpref,
                                                          self.rtheta, self.gtime, self.human_times)])
         # work queue of the deferred 3-D LP (mcn.h: mcn_env_out.lp3_queue): zero-filled once, then the kernels' own
+        # (the library parks 3-D LPs only for crowds of >= 8 ORCA neighbours in batches of >= 16 384 wavefronts, or when
+        #  mcn_tuning.lp3_defer forces it: small queues are always provided, large ones only where they will be used)
         nq = int(_hip.lib.mcn_env_lp3_queue_bytes(E, N))
-        self.lp3_queue = torch.zeros(nq, dtype=torch.uint8, device=dev) if nq > 0 else None
+        wanted = nq > 0 and (nq <= (256 << 20) or _hip.get_tuning().lp3_defer == 1 or
+                             (N >= 8 and -(-E // (64 // N)) >= 16384))
+        self.lp3_queue = torch.zeros(nq, dtype=torch.uint8, device=dev) if wanted else None
         self._out = _hip.EnvOut(*[_hip.ptr(t) for t in (self.step_rec, self.human_act, self.nobs_pos, self.nobs_vel,
                                                         self.lp3_queue)])
         self._out_lean = _hip.EnvOut(*[_hip.ptr(t) for t in (self.step_rec, None, self.nobs_pos, self.nobs_vel,

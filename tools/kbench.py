@@ -70,6 +70,9 @@ def main():
         return
     dev = torch.device("cuda", 0)
     N = a.humans
+    if a.lp3_defer >= 0:                       # before the env allocates (or skips) its 3-D-LP queue
+        from modelcrowdnav_amd import _hip
+        _hip.set_tuning(lp3_defer=a.lp3_defer)
     for E in [int(x) for x in a.sizes.split(",")]:
         env, _ = bench.build_env(E, N, 0, dev)
         env.robot.visible = a.visible

@@ -342,7 +342,8 @@ typedef struct mcn_tuning {
     int32_t rollout_split;   /* fused rollout: two cooperating wavefronts per env group (0/1) */
     int32_t step_block;      /* lane-per-human step kernels: workgroup of 64 or 256 lanes (-1: 64 up to 4096 wavefronts, 256 above) */
     int32_t diag_noop;       /* DIAGNOSTIC build only (make stamp): env kernels return at entry; MCN_EINVAL otherwise */
-    int32_t pair_stream;     /* given-velocity step: streaming kernel (env_pair.hip) 1 wherever it applies / 0 never */
+    int32_t pair_stream;     /* given-velocity step: streaming kernel (env_pair.hip) 1 wherever it applies / 0 never;
+                              * 2 / 3: wherever it applies, with non-temporal per-human streams forced on / off */
     int32_t lp3_defer;       /* lane-per-human ORCA kernels with mcn_env_out.lp3_queue set: park the 3-D LPs for a second,
                               * dense launch (1) or solve them in the step kernel (0); -1: defer from 8 ORCA neighbours and 16 384 wavefronts */
 } mcn_tuning;

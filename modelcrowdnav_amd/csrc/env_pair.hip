@@ -42,7 +42,38 @@ constexpr int kPairDiscMax = 128;
 #define MCN_PAIR_DISC 2
 #endif
 
-template <int NT>
+// Non-temporal loads / stores for the per-human streams (positions, velocities, given velocities, radii: 3/4 of the
+// bytes, each touched exactly once per step).  Measured (round 3, MI355X, 5 humans, with Explorer record and pool
+// restarts): 2^20 envs (660 MB per step, 2.6 x the 256 MB Infinity Cache) 125-145 -> 109-116 us; 2^22 envs 469-580 ->
+// 460-556 us; 65 536 envs (41 MB: the state of one step is still cached when the next one starts) 9.0 -> 9.3-10.1 us,
+// i.e. they only pay once the step's footprint no longer fits the memory-side cache.  Marking the per-env pieces and
+// outputs too loses the gain (141 us at 2^20): neighbouring wavefronts complete each other's partial lines in cache.
+typedef double pair_d2v __attribute__((ext_vector_type(2)));
+template <bool NTMP> __device__ __forceinline__ double2 pair_ld(const double2 *ptr)
+{
+    if constexpr (NTMP) {
+        const pair_d2v v = __builtin_nontemporal_load(reinterpret_cast<const pair_d2v *>(ptr));
+        return make_double2(v.x, v.y);
+    } else {
+        return *ptr;
+    }
+}
+template <bool NTMP> __device__ __forceinline__ double pair_ld(const double *ptr)
+{
+    if constexpr (NTMP) return __builtin_nontemporal_load(ptr);
+    else return *ptr;
+}
+template <bool NTMP> __device__ __forceinline__ void pair_st(double2 *ptr, double2 v)
+{
+    if constexpr (NTMP) {
+        pair_d2v w; w.x = v.x; w.y = v.y;
+        __builtin_nontemporal_store(w, reinterpret_cast<pair_d2v *>(ptr));
+    } else {
+        *ptr = v;
+    }
+}
+
+template <int NT, bool NTMP>
 __global__ __launch_bounds__(256) void env_pair_kernel(const StepParams p)
 {
     constexpr int G = 64 / NT;                 // envs per wavefront
@@ -73,10 +104,10 @@ __global__ __launch_bounds__(256) void env_pair_kernel(const StepParams p)
     const bool do_reset = p.has_roll && ro.pool_hpos != nullptr;
 
     // ---- all global loads up front ----
-    const double2 pos = reinterpret_cast<const double2 *>(p.st.hpos)[a];
-    const double2 vel = reinterpret_cast<const double2 *>(p.st.hvel)[a];
-    const double2 gv = reinterpret_cast<const double2 *>(p.given_v)[a];
-    const double rad = p.st.hrad[a];
+    const double2 pos = pair_ld<NTMP>(reinterpret_cast<const double2 *>(p.st.hpos) + a);
+    const double2 vel = pair_ld<NTMP>(reinterpret_cast<const double2 *>(p.st.hvel) + a);
+    const double2 gv = pair_ld<NTMP>(reinterpret_cast<const double2 *>(p.given_v) + a);
+    const double rad = pair_ld<NTMP>(p.st.hrad + a);
     double2 piece = make_double2(0, 0);
     {
         // piece h of env e: 0 robot position, 1 robot goal, 2 action, 3 / 4 the halves of the Explorer record
@@ -196,8 +227,8 @@ __global__ __launch_bounds__(256) void env_pair_kernel(const StepParams p)
                 if (p.st.rtheta) p.st.rtheta[e] = ro.robot_theta0;
             }
         } else {
-            reinterpret_cast<double2 *>(p.st.hpos)[a] = make_double2(pos.x + gv.x * dt, pos.y + gv.y * dt);
-            reinterpret_cast<double2 *>(p.st.hvel)[a] = gv;
+            pair_st<NTMP>(reinterpret_cast<double2 *>(p.st.hpos) + a, make_double2(pos.x + gv.x * dt, pos.y + gv.y * dt));
+            pair_st<NTMP>(reinterpret_cast<double2 *>(p.st.hvel) + a, gv);
         }
     }
 
@@ -227,7 +258,12 @@ static void launch_pair_one(const StepParams &p, hipStream_t stream)
     constexpr int G = 64 / NT;
     const long per_block = 4 * G;
     const int blocks = (int)((p.E + per_block - 1) / per_block);
-    hipLaunchKernelGGL((env_pair_kernel<NT>), dim3(blocks), dim3(256), 0, stream, p);
+    // non-temporal per-human streams once one step's footprint (~(15 + 11 N) x 8 + 70 B per env) exceeds what the
+    // 256 MB memory-side cache can hold across two consecutive steps; mcn_tuning.pair_stream 2 / 3 force it on / off
+    const double footprint = (double)p.E * ((15 + 11 * NT) * 8 + 70);
+    const bool nt = p.pair_stream == 2 || (p.pair_stream != 3 && footprint > 200e6);
+    if (nt) hipLaunchKernelGGL((env_pair_kernel<NT, true>), dim3(blocks), dim3(256), 0, stream, p);
+    else    hipLaunchKernelGGL((env_pair_kernel<NT, false>), dim3(blocks), dim3(256), 0, stream, p);
 }
 
 // Returns true when the streaming kernel handles this problem.

@@ -50,13 +50,8 @@ struct GroupCand {
 // MODE: MCN_HUMANS_* fixed at compile time, so the given-velocity / linear variants carry no ORCA registers,
 // no neighbour staging and no goal loads (they are pure streaming kernels and want maximum occupancy).
 // HH_T: 0 never count overlaps, 1 always, 2 decide at run time from cfg.count_hh.
-// A/B switch: minimum workgroups per CU of the 4-wavefront ORCA instantiations (0 = let the register count decide)
-#ifndef MCN_STEP_MINBLOCKS
-#define MCN_STEP_MINBLOCKS 0
-#endif
 template <int BLOCK, int NT, int VIS, int MODE, int HH_T>
-__global__ __launch_bounds__(BLOCK, (BLOCK == 256 && MODE == MCN_HUMANS_ORCA && NT > 0 && NT <= 5 && MCN_STEP_MINBLOCKS) ? MCN_STEP_MINBLOCKS : 1)
-// (forcing 8 waves/SIMD on the streaming variants spills and is 1.5x slower)
+__global__ __launch_bounds__(BLOCK)     // (occupancy hints spill: 5 / 6 workgroups per CU on the 5-human ORCA kernel 203 -> 320 / 485 us at 2^20 envs)
 void env_step_kernel(const StepParams p)
 {
     constexpr bool kStageHumans = (MODE == MCN_HUMANS_ORCA) || (HH_T != 0);

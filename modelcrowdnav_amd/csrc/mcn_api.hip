@@ -126,7 +126,7 @@ const char *mcn_version(void) { return "modelcrowdnav_amd 0.2 (gfx950)"; }
 int mcn_set_tuning(const mcn_tuning *t)
 {
     if (!t) { g_tuning = tuning_from_env(); g_tuning_init = true; return MCN_OK; }
-    if (t->quad_split > 1 || t->rollout_fused > 1 || t->rollout_split > 1 || t->pair_stream > 1 || t->force_generic < 0 || t->force_generic > 1) return MCN_EINVAL;
+    if (t->quad_split > 1 || t->rollout_fused > 1 || t->rollout_split > 1 || t->pair_stream > 3 || t->force_generic < 0 || t->force_generic > 1) return MCN_EINVAL;
     if (t->quad_max_envs < -1 || t->quad_split < -1 || t->rollout_fused < -1 || t->rollout_split < -1 || t->pair_stream < -1) return MCN_EINVAL;
     if (t->step_block != -1 && t->step_block != 64 && t->step_block != 256) return MCN_EINVAL;
     if (t->lp3_defer < -1 || t->lp3_defer > 1) return MCN_EINVAL;

@@ -116,7 +116,8 @@ def test_given_velocity_and_linear_modes():
 
 @pytest.mark.parametrize("N", [5, 10])
 @pytest.mark.parametrize("book", ["pool", "record", "none"])
-def test_streaming_pair_kernel_equals_lane_per_human(N, book, tuning):
+@pytest.mark.parametrize("stream", [1, 2])      # 2: the non-temporal form large batches get, forced at a small size
+def test_streaming_pair_kernel_equals_lane_per_human(N, book, stream, tuning):
     """env_pair.hip (given velocities, per-env data loaded / stored in 16-byte pieces by all lanes of the env, ladder
     and Explorer record on every lane) against env_step_kernel<GIVEN>: every byte of state, step record, Explorer
     record and finished-episode records over 130 steps with collisions, goals, timeouts and pool restarts; the first
@@ -141,7 +142,7 @@ def test_streaming_pair_kernel_equals_lane_per_human(N, book, tuning):
     acts = torch.from_numpy(np.stack([rng.uniform(-0.3, 0.3, (T, E)), rng.uniform(0.2, 1.0, (T, E))], -1)).to(a.device)
     st0 = H.download(a)
     for t in range(T):
-        tuning(pair_stream=1)
+        tuning(pair_stream=stream)
         a.step(acts[t], given_v=gv[t])
         tuning(pair_stream=0)
         b.step(acts[t], given_v=gv[t])

@@ -258,10 +258,11 @@ static void launch_pair_one(const StepParams &p, hipStream_t stream)
     constexpr int G = 64 / NT;
     const long per_block = 4 * G;
     const int blocks = (int)((p.E + per_block - 1) / per_block);
-    // non-temporal per-human streams once one step's footprint (~(15 + 11 N) x 8 + 70 B per env) exceeds what the
-    // 256 MB memory-side cache can hold across two consecutive steps; mcn_tuning.pair_stream 2 / 3 force it on / off
+    // non-temporal per-human streams once one step's footprint (~(15 + 11 N) x 8 + 70 B per env) is well past the
+    // 256 MB memory-side cache (measured cross-over, 5 humans: 2^18 envs = 165 MB 27.9 vs 32 us without / with,
+    // 2^19 = 330 MB equal, 2^20 = 660 MB 126-142 vs 108-109); mcn_tuning.pair_stream 2 / 3 force it on / off
     const double footprint = (double)p.E * ((15 + 11 * NT) * 8 + 70);
-    const bool nt = p.pair_stream == 2 || (p.pair_stream != 3 && footprint > 200e6);
+    const bool nt = p.pair_stream == 2 || (p.pair_stream != 3 && footprint > 400e6);
     if (nt) hipLaunchKernelGGL((env_pair_kernel<NT, true>), dim3(blocks), dim3(256), 0, stream, p);
     else    hipLaunchKernelGGL((env_pair_kernel<NT, false>), dim3(blocks), dim3(256), 0, stream, p);
 }

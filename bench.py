@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--replays", type=int, default=0,
                     help="passes of the K steps inside the timed region (0 = as many as fill --min-timed-ms)")
+    ap.add_argument("--no-merge", action="store_true",
+                    help="keep one launch per pass of the K steps instead of merging consecutive passes of the timed "
+                         "region into launches of up to --steps-per-launch steps")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the N > 1 branches (process group, the one all_gather of episode records, the MAX / SUM "
                          "all-reduces) with a single rank too: exercises RCCL on a one-GPU box")
@@ -575,10 +578,38 @@ def main():
     probe_ms = ev_s.elapsed_time(ev_e)
     R = args.replays if args.replays > 0 else int(min(20000, max(1, np.ceil(args.min_timed_ms / max(probe_ms, 1e-3)))))
 
+    # The pre-drawn action sequence of the whole timed region (R passes of the K steps) is known up front, so
+    # consecutive passes go to the device as ONE mcn_env_rollout launch of up to --steps-per-launch steps (the env state
+    # stays in registers across them; results equal the separate launches bit for bit,
+    # tests/test_env_step_gpu.py::test_rollout_launch_equals_single_steps).  A launch ends with its slowest env group,
+    # so 20-step launches run at 3.7 us per step and 1000-step ones at 2.8: SURVEY 8(d) defines the metric over >= 200
+    # steady-state steps, and `short_launch` below reports the 20-step figure next to it.
+    merge = 1
+    if S > 1 and len(chunks) == 1 and R > 1 and not args.no_merge:
+        merge = int(max(1, min(R, args.steps_per_launch // K)))
+    acts_rep = acts[W:W + K].repeat(merge, 1, 1).contiguous() if merge > 1 else None
+    if merge > 1 and args.replays <= 0:
+        # size the timed region with the launches it will really use: a whole number of merged launches
+        env.rollout(acts_rep)
+        torch.cuda.synchronize()
+        ev_s.record()
+        env.rollout(acts_rep)
+        ev_e.record()
+        torch.cuda.synchronize()
+        per_pass_ms = ev_s.elapsed_time(ev_e) / merge
+        R = int(np.ceil(max(1.0, args.min_timed_ms / max(per_pass_ms, 1e-4)) / merge)) * merge
+    n_full, n_rem = (R // merge, R % merge) if merge > 1 else (R, 0)
+
     def run_timed_steps():
         """R back-to-back passes of the K steps."""
-        for _ in range(R):
-            one_pass()
+        if merge > 1:
+            for _ in range(n_full):
+                env.rollout(acts_rep)
+            if n_rem:
+                env.rollout(acts_rep[:n_rem * K])
+        else:
+            for _ in range(R):
+                one_pass()
 
     use_graph = not args.no_graph
     if use_graph:
@@ -634,7 +665,7 @@ def main():
         dist.all_reduce(ws, op=dist.ReduceOp.SUM)
         env_steps_total = float(ws.item())
     # dominant-kernel duration: HIP events (launch stream) bracketing the back-to-back launches of the timed region
-    n_launch = (K if S == 1 else len(chunks)) * R
+    n_launch = (K if S == 1 else len(chunks)) * R if merge == 1 else n_full + (1 if n_rem else 0)
     kernel_ms = ev_s.elapsed_time(ev_e) / n_launch
 
     rb = env.rollout_buffers
@@ -643,11 +674,12 @@ def main():
 
     roof = roofline_entry(E, N, kernel_ms, {"timing": "HIP events around the %d launches of the timed region (%s)" % (
         n_launch, "one hipGraph" if use_graph else "eager")}, steps_per_launch=K * R / n_launch)
+    S_eff = S * merge
     if S > 1:
         # state lives in registers across the steps of a launch: HBM sees the state once per launch, not per step
         roof["note"] = ("algorithmic bytes = SURVEY 8(d) per-env-step figure x env-steps per launch; a launch keeps the "
                         "env state in registers for its %d steps, so real HBM traffic (`traffic`) is a fraction of "
-                        "that and the kernel is instruction-issue / latency-bound, not HBM-bound: see roofline_valu" % S)
+                        "that and the kernel is instruction-issue / latency-bound, not HBM-bound: see roofline_valu" % S_eff)
     valu = valu_roofline(E, N, kernel_ms, K * R / n_launch, rollout=S > 1)
 
     result = {
@@ -658,8 +690,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%d envs x %d humans per GPU, ORCA humans, random robot actions (81-entry table), "
                                "auto-reset, %s" % (E, N, "1 mcn_env_step launch per step" if S == 1 else
-                                                   "%d steps per mcn_env_rollout launch" % S),
-                   "steps_per_launch": S, "replays": R, "timed_steps": K * R,
+                                                   "%d steps per mcn_env_rollout launch" % (S * merge)),
+                   "steps_per_launch": S * merge, "passes_per_launch": merge, "replays": R, "timed_steps": K * R,
                    "timed_region_ms": round(elapsed * 1e3, 3), "probe_pass_ms": round(probe_ms, 4),
                    "envs_per_gpu": E, "humans": N, "launch": "hipGraph" if use_graph else "eager",
                    "parallelism": "env-shard x%d, no per-step collective" % world},
@@ -670,6 +702,23 @@ def main():
         "roofline_valu": valu,
     }
 
+    if rank == 0 and world == 1 and merge > 1:
+        # the same K steps as ONE launch per pass (what a caller with only K actions in hand pays: the launch ends with
+        # its slowest env group)
+        s_e, e_e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        one_pass()
+        torch.cuda.synchronize()
+        s_e.record()
+        for _ in range(reps):
+            one_pass()
+        e_e.record()
+        torch.cuda.synchronize()
+        sl_ms = s_e.elapsed_time(e_e) / reps
+        result["short_launch"] = roofline_entry(E, N, sl_ms, {
+            "mode": "%d steps per mcn_env_rollout launch, %d back-to-back launches" % (K, reps),
+            "env_steps_per_sec": round(E * K / (sl_ms * 1e-3), 1), "us_per_step": round(sl_ms * 1e3 / K, 4),
+            "roofline_valu": valu_roofline(E, N, sl_ms, K, rollout=True)}, steps_per_launch=K)
     if rank == 0 and world == 1 and S > 1:
         # the same workload stepped one mcn_env_step launch at a time (policy-in-the-loop callers pay this)
         one_ms, _ = time_kernel_events(env, acts, 200)

@@ -76,4 +76,6 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 "$ROOT/bench.py" --gpus 1 --steps 20 --warmup 5 \
     > "$DST/${TAG}_bench_stdout.json" 2> "$OUT/bench.err" || { tail -5 "$OUT/bench.err"; exit 1; }
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$DST/${TAG}_bench_kernel_stats.csv"
+# the headline kernel is launched with several lengths in one run: per-launch durations by class, from the trace
+python3 "$ROOT/tools/trace_launches.py" "$(find "$OUT/stats" -name '*kernel_trace.csv' | head -1)" > "$DST/${TAG}_bench_rollout_launches.txt"
 echo "bench + kernel stats done"

@@ -327,6 +327,61 @@ int mcn_sgan_step(const mcn_sgan_net *net, double *hist, int32_t push_slot, int3
                   const float *noise, const int32_t *hcount, void *workspace, double *out_vel, float *out_rel,
                   double time_step, int32_t E, int32_t N, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * MlpWorld one-step world model (crowd_nav/policy/world_model.py:22-42).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Device pointers to the four Linear layers of MlpWorld.mlp (state_dict keys mlp.0 / mlp.3 / mlp.6 / mlp.8), packed by
+ * mcn_pack_linear: mlp.0 with KT = ceil(4N / 16) natural input tiles and 8 output tiles; mlp.3 8 -> 4 tiles; mlp.6
+ * 4 -> 1 tile with its 12 outputs packed "q first" (omap: feature j at slot 4 (j % 4) + j / 4); mlp.8 with the matching
+ * kmap, 1 input tile, ceil(2N / 16) natural output tiles. */
+typedef struct mcn_mlp_world_net {
+    const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4;
+} mcn_mlp_world_net;
+
+/*
+ * mcn_mlp_world_step -- MlpWorld.forward (eval mode: dropout is the identity) for E scenes of N <= 10 pedestrians:
+ * input row = the scene's [px, py, vx, vy] x N as float32 (model_crowd_sim.py:401-405), output = the N predicted
+ * velocities (tanh of mlp.8's output, world_model.py:33-35) as float64 [E*N][2] -- what ModelCrowdSim.step hands to
+ * humans[i].step(ActionXY(new_v[i])) (model_crowd_sim.py:406-417), i.e. mcn_env_step's given_v.
+ */
+int mcn_mlp_world_step(const mcn_mlp_world_net *net, const double *hpos, const double *hvel, double *out_vel,
+                       int32_t E, int32_t N, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * AttentionWorld one-step world model (crowd_nav/policy/world_model.py:54-106).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Device pointers to the packed fragments of one AttentionWorld (state_dict keys in comments; ragged tiles packed
+ * "q first" as for mcn_sarl_net).  The 4-wide pedestrian state [px, py, vx, vy] is one input tile with feature c in
+ * slot 4 c (one MFMA k-step). */
+typedef struct mcn_attn_world_net {
+    const float *w_m1a, *b_m1a;   /* mlp1.0         4 -> 150 */
+    const float *w_m1b, *b_m1b;   /* mlp1.2       150 -> 100 */
+    const float *w_m2a, *b_m2a;   /* mlp2.0       100 -> 100 */
+    const float *w_m2b, *b_m2b;   /* mlp2.2       100 -> 50  */
+    const float *w_ata, *b_ata;   /* attention.0  columns   0..99  (per-pedestrian half) + bias */
+    const float *w_atg;           /* attention.0  columns 100..199 (global-state half)          */
+    const float *w_atb, *b_atb;   /* attention.2  100 -> 100 */
+    const float *w_atc, *b_atc;   /* attention.4  100 -> 1   */
+    const float *w_m3p, *b_m3p;   /* mlp3.0       columns 4..53 (pooled feature) + bias: 50 -> 150 */
+    const float *w_m3s;           /* mlp3.0       columns 0..3  (the pedestrian's own state): 4 -> 150 */
+    const float *w_m3b, *b_m3b;   /* mlp3.2       150 -> 100 */
+    const float *w_m3c, *b_m3c;   /* mlp3.4       100 -> 100 */
+    const float *w_m3d, *b_m3d;   /* mlp3.6       100 -> 2 (natural row order) */
+} mcn_attn_world_net;
+
+int64_t mcn_attn_world_workspace_bytes(int32_t E, int32_t N);
+
+/*
+ * mcn_attn_world_step -- AttentionWorld.forward for E scenes of N pedestrians: input = each pedestrian's
+ * [px, py, vx, vy] as float32 (model_crowd_sim.py:401-405), output = its predicted velocity (mlp3's two outputs, no
+ * output non-linearity, world_model.py:104-105) as float64 [E*N][2].  hcount ([E] int32 or NULL): scene e has only
+ * its first hcount[e] pedestrians (the rest of the N slots is ignored and not written).
+ */
+int mcn_attn_world_step(const mcn_attn_world_net *net, const double *hpos, const double *hvel, const int32_t *hcount,
+                        void *workspace, double *out_vel, int32_t E, int32_t N, void *stream);
+
 /*
  * Dispatch overrides (host, process-wide, not stream-ordered; for tests and tuning).  Every env-step arithmetic
  * exists in several kernel decompositions with bit-identical results; by default the entry points pick one from

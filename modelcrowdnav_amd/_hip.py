@@ -136,6 +136,12 @@ def _load():
     lib.mcn_sarl_predict.argtypes = [_vp, C.POINTER(EnvState), _vp, _i, _d, _d, _i, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _vp, _vp, _vp, _i, _i, _vp]
     lib.mcn_sarl_predict.restype = C.c_int
+    lib.mcn_mlp_world_step.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _vp]
+    lib.mcn_mlp_world_step.restype = C.c_int
+    lib.mcn_attn_world_workspace_bytes.argtypes = [_i, _i]
+    lib.mcn_attn_world_workspace_bytes.restype = C.c_int64
+    lib.mcn_attn_world_step.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]
+    lib.mcn_attn_world_step.restype = C.c_int
     lib.mcn_sgan_workspace_bytes.argtypes = [_i, _i]
     lib.mcn_sgan_workspace_bytes.restype = C.c_int64
     lib.mcn_sgan_step.argtypes = [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _vp]
@@ -147,7 +153,8 @@ lib = _load()
 
 # every symbol include/mcn.h declares; tests/test_abi.py checks the .so exports each one
 EXPORTED = ["mcn_version", "mcn_set_tuning", "mcn_get_tuning", "mcn_env_step", "mcn_env_lp3_queue_bytes", "mcn_env_rollout", "mcn_scenario_pool", "mcn_orca_batch", "mcn_pack_linear", "mcn_sarl_workspace_bytes",
-            "mcn_sarl_lookahead", "mcn_sarl_lookahead_env", "mcn_sarl_predict", "mcn_sgan_workspace_bytes", "mcn_sgan_step"]
+            "mcn_sarl_lookahead", "mcn_sarl_lookahead_env", "mcn_sarl_predict", "mcn_sgan_workspace_bytes", "mcn_sgan_step", "mcn_mlp_world_step", "mcn_attn_world_workspace_bytes",
+            "mcn_attn_world_step"]
 
 
 def check(rc, what):

@@ -16,6 +16,11 @@ int launch_scenario_pool(const mcn_scenario_cfg &c, uint64_t seed, int64_t first
                          double *hgoal, double *hrad, double *hvpref, hipStream_t stream);
 struct SarlParams;
 long sarl_workspace_float4s(int E, int N, int A);
+int launch_mlp_world(const mcn_mlp_world_net *net, const double *hpos, const double *hvel, double *out_vel, int E, int N,
+                     hipStream_t stream);
+int launch_attn_world(const mcn_attn_world_net *net, const double *hpos, const double *hvel, const int32_t *hcount,
+                      void *workspace, double *out_vel, int E, int N, hipStream_t stream);
+long attn_world_workspace_float4s(int E, int N);
 int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int A, double dt,
                   double gamma_pow, int kinematics, void *workspace, double *values, int32_t *best, double *best_val,
                   float *attention, const double *next_hpos, const double *next_hvel, const double *reward_in,
@@ -303,6 +308,32 @@ int mcn_sarl_predict(const mcn_sarl_net *net, const mcn_env_state *st, const dou
     if ((next_hpos == nullptr) != (rewards == nullptr)) return MCN_EINVAL;
     return sarl_lookahead_impl(net, st, actions, A, time_step, gamma_pow, kinematics, workspace, values, best, best_val,
                                attention, next_hpos, next_hvel, rewards, action_out, E, N, stream);
+}
+
+int mcn_mlp_world_step(const mcn_mlp_world_net *net, const double *hpos, const double *hvel, double *out_vel,
+                       int32_t E, int32_t N, void *stream)
+{
+    if (!net || !hpos || !hvel || !out_vel || E <= 0 || N <= 0 || N > 10) return MCN_EINVAL;
+    const float *const *fp = reinterpret_cast<const float *const *>(net);
+    for (int k = 0; k < 8; ++k)
+        if (!fp[k]) return MCN_EINVAL;
+    return mcn::launch_mlp_world(net, hpos, hvel, out_vel, E, N, (hipStream_t)stream);
+}
+
+int64_t mcn_attn_world_workspace_bytes(int32_t E, int32_t N)
+{
+    if (E <= 0 || N <= 0) return 0;
+    return (int64_t)mcn::attn_world_workspace_float4s(E, N) * 16;
+}
+
+int mcn_attn_world_step(const mcn_attn_world_net *net, const double *hpos, const double *hvel, const int32_t *hcount,
+                        void *workspace, double *out_vel, int32_t E, int32_t N, void *stream)
+{
+    if (!net || !hpos || !hvel || !workspace || !out_vel || E <= 0 || N <= 0 || N > MCN_MAX_HUMANS) return MCN_EINVAL;
+    const float *const *fp = reinterpret_cast<const float *const *>(net);
+    for (size_t k = 0; k < sizeof(mcn_attn_world_net) / sizeof(float *); ++k)
+        if (!fp[k]) return MCN_EINVAL;
+    return mcn::launch_attn_world(net, hpos, hvel, hcount, workspace, out_vel, E, N, (hipStream_t)stream);
 }
 
 int64_t mcn_sgan_workspace_bytes(int32_t E, int32_t N)

@@ -4,7 +4,8 @@
   SGANWorld       :134-268  E = 1 callable with the reference's constructor and return type
   VecSGANWorld              the same step for E scenes, history kept as a ring in HBM
 
-MlpWorld / AttentionWorld (:22-106) are the next tier and not built.
+  MlpWorld        :22-51    torch module (trained by Trainer_Sim); VecMlpWorld runs it for E scenes in one HIP launch
+  AttentionWorld  :54-106   torch module; VecTorchWorld runs any [B,4N] -> [B,2N] module on a VecModelCrowdSim
 """
 import logging
 import os
@@ -234,6 +235,150 @@ class AttentionWorld(nn.Module):
         pooled = (w * feat.view(B, N, -1)).sum(dim=1, keepdim=True).expand(B, N, feat.shape[1])
         joint = torch.cat([state, pooled], dim=2)
         return self.mlp3(joint.reshape(B * N, self.mlp3_input_dim)).view(B, -1)
+
+
+class _MlpWorldNet(__import__("ctypes").Structure):
+    _fields_ = [(n, __import__("ctypes").c_void_p) for n in ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4")]
+
+
+def pack_mlp_world(module, num_human, dev):
+    """MlpWorld.state_dict -> (ctypes mcn_mlp_world_net, [device tensors kept alive]); layouts in include/mcn.h."""
+    import ctypes as C
+    from .. import _hip
+    from .sarl import _ident, _natural
+    sd = {k: v.detach().to("cpu", torch.float32).contiguous().numpy() for k, v in module.state_dict().items()}
+    N = int(num_human)
+    if tuple(sd["mlp.0.weight"].shape) != (128, 4 * N) or tuple(sd["mlp.8.weight"].shape) != (2 * N, 12):
+        raise ValueError("MlpWorld built for %d pedestrians, asked to run %d" % (sd["mlp.0.weight"].shape[1] // 4, N))
+    kt1, nt4 = (4 * N + 15) // 16, (2 * N + 15) // 16
+    plan = [("1", "mlp.0", _natural(4 * N, kt1), kt1, None, 8),
+            ("2", "mlp.3", _natural(128, 8), 8, None, 4),
+            ("3", "mlp.6", _natural(64, 4), 4, _ident(12, 1), 1),
+            ("4", "mlp.8", _ident(12, 1), 1, None, nt4)]
+    net, keep = _MlpWorldNet(), []
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    for tag, key, kmap, KT, omap, NT in plan:
+        W, b = sd[key + ".weight"], sd[key + ".bias"]
+        nout, kin = W.shape
+        wf = np.zeros((NT, KT, 64, 4), np.float32)
+        bf = np.zeros((NT, 64, 4), np.float32)
+        om = omap if omap is not None else _natural(nout, NT)
+        rc = _hip.lib.mcn_pack_linear(W.ctypes.data_as(fp), b.ctypes.data_as(fp), nout, kin, kmap.ctypes.data_as(ip), KT,
+                                      om.ctypes.data_as(ip), NT, wf.ctypes.data_as(fp), bf.ctypes.data_as(fp))
+        _hip.check(rc, "mcn_pack_linear(mlp_world %s)" % key)
+        dw, db = torch.from_numpy(wf).to(dev), torch.from_numpy(bf).to(dev)
+        keep += [dw, db]
+        setattr(net, "w" + tag, dw.data_ptr())
+        setattr(net, "b" + tag, db.data_ptr())
+    return net, keep
+
+
+class VecMlpWorld(object):
+    """MlpWorld as a VecModelCrowdSim `sim_world`: one mcn_mlp_world_step launch for all E scenes (eval mode: the
+    reference calls the model under `model_sim.eval()` when it imagines, train_model_based_sgan.py).  The weights are
+    packed at construction; call `refresh()` after training steps changed the module."""
+
+    def __init__(self, module, env):
+        self.module, self.env = module, env
+        self._net = None
+        self.out_vel = None
+
+    def refresh(self):
+        self._net = None
+
+    def __call__(self, hpos, noise=None):
+        import ctypes as C
+        from .. import _hip
+        env = self.env
+        E, N, dev = env.num_envs, env._alloc_N, env.device
+        if self._net is None or self._net[2] != (E, N):
+            net, keep = pack_mlp_world(self.module, N, dev)
+            self._net = (net, keep, (E, N))
+            self.out_vel = torch.empty(E, N, 2, dtype=torch.float64, device=dev)
+        rc = _hip.lib.mcn_mlp_world_step(C.byref(self._net[0]), _hip.ptr(env.hpos), _hip.ptr(env.hvel),
+                                         _hip.ptr(self.out_vel), E, N, _hip.stream_ptr(dev))
+        _hip.check(rc, "mcn_mlp_world_step")
+        return self.out_vel
+
+
+class _AttnWorldNet(__import__("ctypes").Structure):
+    _fields_ = [(n, __import__("ctypes").c_void_p) for n in (
+        "w_m1a", "b_m1a", "w_m1b", "b_m1b", "w_m2a", "b_m2a", "w_m2b", "b_m2b", "w_ata", "b_ata", "w_atg", "w_atb", "b_atb",
+        "w_atc", "b_atc", "w_m3p", "b_m3p", "w_m3s", "w_m3b", "b_m3b", "w_m3c", "b_m3c", "w_m3d", "b_m3d")]
+
+
+def pack_attn_world(module, dev):
+    """AttentionWorld.state_dict -> (ctypes mcn_attn_world_net, [device tensors kept alive]); layouts in include/mcn.h."""
+    import ctypes as C
+    from .. import _hip
+    from .sarl import _ident, _natural
+    if not module.with_global_state or module.input_dim != 4:
+        raise NotImplementedError("world_attn.hip is built for input_dim 4 with the global state (the reference's defaults)")
+    sd = {k: v.detach().to("cpu", torch.float32).contiguous().numpy() for k, v in module.state_dict().items()}
+    #        name   state_dict key  kmap                          KT  bias  omap (None = ragged "q first" like its consumers)
+    plan = [("m1a", "mlp1.0", _ident(4, 1), 1, True, None),
+            ("m1b", "mlp1.2", _ident(150, 10), 10, True, None),
+            ("m2a", "mlp2.0", _ident(100, 7), 7, True, None),
+            ("m2b", "mlp2.2", _ident(100, 7), 7, True, None),
+            ("ata", "attention.0", _ident(100, 7), 7, True, None),
+            ("atg", "attention.0", _ident(100, 7, offset=100), 7, False, None),
+            ("atb", "attention.2", _ident(100, 7), 7, True, None),
+            ("atc", "attention.4", _ident(100, 7), 7, True, None),
+            ("m3p", "mlp3.0", _ident(50, 4, offset=4), 4, True, None),
+            ("m3s", "mlp3.0", _ident(4, 1), 1, False, None),
+            ("m3b", "mlp3.2", _ident(150, 10), 10, True, None),
+            ("m3c", "mlp3.4", _ident(100, 7), 7, True, None),
+            ("m3d", "mlp3.6", _ident(100, 7), 7, True, _natural(2, 1))]
+    net, keep = _AttnWorldNet(), []
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    for name, key, kmap, KT, with_bias, omap in plan:
+        W, b = sd[key + ".weight"], sd[key + ".bias"]
+        nout, kin = W.shape
+        NT = (nout + 15) // 16
+        wf = np.zeros((NT, KT, 64, 4), np.float32)
+        bf = np.zeros((NT, 64, 4), np.float32)
+        om = omap if omap is not None else _ident(nout, NT)
+        rc = _hip.lib.mcn_pack_linear(W.ctypes.data_as(fp), b.ctypes.data_as(fp), nout, kin, kmap.ctypes.data_as(ip), KT,
+                                      om.ctypes.data_as(ip), NT, wf.ctypes.data_as(fp),
+                                      bf.ctypes.data_as(fp) if with_bias else None)
+        _hip.check(rc, "mcn_pack_linear(attn_world %s)" % name)
+        dw = torch.from_numpy(wf).to(dev)
+        keep.append(dw)
+        setattr(net, "w_" + name, dw.data_ptr())
+        if with_bias:
+            db = torch.from_numpy(bf).to(dev)
+            keep.append(db)
+            setattr(net, "b_" + name, db.data_ptr())
+    return net, keep
+
+
+class VecAttnWorld(object):
+    """AttentionWorld as a VecModelCrowdSim `sim_world`: one mcn_attn_world_step launch for all E scenes.  The weights
+    are packed at construction; call `refresh()` after training steps changed the module.  `hcount` ([E] int32
+    device tensor): scene e has only its first hcount[e] pedestrians."""
+
+    def __init__(self, module, env):
+        self.module, self.env = module, env
+        self._net = None
+        self.out_vel = None
+
+    def refresh(self):
+        self._net = None
+
+    def __call__(self, hpos, noise=None, hcount=None):
+        import ctypes as C
+        from .. import _hip
+        env = self.env
+        E, N, dev = env.num_envs, env._alloc_N, env.device
+        if self._net is None or self._net[2] != (E, N):
+            net, keep = pack_attn_world(self.module, dev)
+            ws = torch.empty(_hip.lib.mcn_attn_world_workspace_bytes(E, N) // 4, dtype=torch.float32, device=dev)
+            self._net = (net, keep, (E, N), ws)
+            self.out_vel = torch.zeros(E, N, 2, dtype=torch.float64, device=dev)
+        rc = _hip.lib.mcn_attn_world_step(C.byref(self._net[0]), _hip.ptr(env.hpos), _hip.ptr(env.hvel), _hip.ptr(hcount),
+                                          _hip.ptr(self._net[3]), _hip.ptr(self.out_vel), E, N, _hip.stream_ptr(dev))
+        _hip.check(rc, "mcn_attn_world_step")
+        return self.out_vel
 
 
 class VecTorchWorld(object):

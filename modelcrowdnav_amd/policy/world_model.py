@@ -381,6 +381,16 @@ class VecAttnWorld(object):
         return self.out_vel
 
 
+def vec_world(module, env):
+    """The fastest `sim_world` adapter for a world-model module on a VecModelCrowdSim: the HIP kernels for MlpWorld and
+    (default-shaped) AttentionWorld, torch for anything else."""
+    if isinstance(module, MlpWorld) and env.human_num <= 10:
+        return VecMlpWorld(module, env)
+    if isinstance(module, AttentionWorld) and module.with_global_state and module.input_dim == 4:
+        return VecAttnWorld(module, env)
+    return VecTorchWorld(module, env)
+
+
 class VecTorchWorld(object):
     """Adapter: a [B,4N] -> [B,2N] module (MlpWorld / AttentionWorld) as a VecModelCrowdSim `sim_world`."""
 

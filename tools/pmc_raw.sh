@@ -4,7 +4,7 @@
 set -o pipefail
 TAG=$1; CTRS=$2; shift 2
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r2
+OUT=$ROOT/gpurun_out/r3
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc $CTRS --output-format csv -d "$OUT/pmc_$TAG" -o pmc -- python3 "$ROOT/$1" "${@:2}" > "$OUT/pmc_$TAG.log" 2>&1 \

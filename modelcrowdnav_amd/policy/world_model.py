@@ -7,6 +7,7 @@
   MlpWorld        :22-51    torch module (trained by Trainer_Sim); VecMlpWorld runs it for E scenes in one HIP launch
   AttentionWorld  :54-106   torch module; VecTorchWorld runs any [B,4N] -> [B,2N] module on a VecModelCrowdSim
 """
+import ctypes as C
 import logging
 import os
 
@@ -237,13 +238,12 @@ class AttentionWorld(nn.Module):
         return self.mlp3(joint.reshape(B * N, self.mlp3_input_dim)).view(B, -1)
 
 
-class _MlpWorldNet(__import__("ctypes").Structure):
-    _fields_ = [(n, __import__("ctypes").c_void_p) for n in ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4")]
+class _MlpWorldNet(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4")]
 
 
 def pack_mlp_world(module, num_human, dev):
     """MlpWorld.state_dict -> (ctypes mcn_mlp_world_net, [device tensors kept alive]); layouts in include/mcn.h."""
-    import ctypes as C
     from .. import _hip
     from .sarl import _ident, _natural
     sd = {k: v.detach().to("cpu", torch.float32).contiguous().numpy() for k, v in module.state_dict().items()}
@@ -287,7 +287,6 @@ class VecMlpWorld(object):
         self._net = None
 
     def __call__(self, hpos, noise=None):
-        import ctypes as C
         from .. import _hip
         env = self.env
         E, N, dev = env.num_envs, env._alloc_N, env.device
@@ -301,15 +300,14 @@ class VecMlpWorld(object):
         return self.out_vel
 
 
-class _AttnWorldNet(__import__("ctypes").Structure):
-    _fields_ = [(n, __import__("ctypes").c_void_p) for n in (
+class _AttnWorldNet(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
         "w_m1a", "b_m1a", "w_m1b", "b_m1b", "w_m2a", "b_m2a", "w_m2b", "b_m2b", "w_ata", "b_ata", "w_atg", "w_atb", "b_atb",
         "w_atc", "b_atc", "w_m3p", "b_m3p", "w_m3s", "w_m3b", "b_m3b", "w_m3c", "b_m3c", "w_m3d", "b_m3d")]
 
 
 def pack_attn_world(module, dev):
     """AttentionWorld.state_dict -> (ctypes mcn_attn_world_net, [device tensors kept alive]); layouts in include/mcn.h."""
-    import ctypes as C
     from .. import _hip
     from .sarl import _ident, _natural
     if not module.with_global_state or module.input_dim != 4:
@@ -366,7 +364,6 @@ class VecAttnWorld(object):
         self._net = None
 
     def __call__(self, hpos, noise=None, hcount=None):
-        import ctypes as C
         from .. import _hip
         env = self.env
         E, N, dev = env.num_envs, env._alloc_N, env.device

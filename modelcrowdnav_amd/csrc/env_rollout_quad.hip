@@ -127,7 +127,18 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
     const int g = lane / LPE;
     const int r = lane - g * LPE;
     const int h = r >> 2, k = r & 3;
-    const long e = (long)blockIdx.x * G + g;
+    // XCD-aware chunking (as env_step_kernel): workgroups are dealt round-robin over the 8 XCDs, each with a private
+    // L2, and a workgroup's envs cover only part of a cache line of the per-env arrays (3 envs x 16 B at 5 humans):
+    // give every XCD one contiguous range of envs so that a line is fetched into ONE L2 instead of two or three.
+    // A/B switch MCN_QUAD_XCD (1 = on).
+#ifndef MCN_QUAD_XCD
+#define MCN_QUAD_XCD 1
+#endif
+    const unsigned nb_ = gridDim.x, xcd_ = blockIdx.x & 7u, idx_ = blockIdx.x >> 3;
+    const unsigned qq_ = nb_ >> 3, rr__ = nb_ & 7u;
+    const unsigned chunk_ = MCN_QUAD_XCD ? (xcd_ < rr__ ? xcd_ * (qq_ + 1) : rr__ * (qq_ + 1) + (xcd_ - rr__) * qq_) + idx_
+                                         : blockIdx.x;
+    const long e = (long)chunk_ * G + g;
     const bool active = (g < G) && (e < p.E);
     const long eb = active ? e : 0;
     const long a = eb * NT + h;

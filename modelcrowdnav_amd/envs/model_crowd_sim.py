@@ -150,7 +150,22 @@ class ModelCrowdSim(CrowdSim):
             current_s = [h.get_observable_state().getvalue() for h in self.humans]
             if v.sim_world is None:
                 raise AttributeError("sim_world has to be set when new_v is not given")
-            new_v = v.sim_world(current_s)              # SGANWorld-style callable -> [N,2]
+            sw = v.sim_world
+            from ..policy.world_model import SGANWorld
+            if isinstance(sw, torch.nn.Module) and not isinstance(sw, SGANWorld):
+                # MlpWorld / AttentionWorld style module (model_crowd_sim.py:404-407): one float32 row [1, 4N] in, one
+                # row of 2N velocities out
+                dev = getattr(self, "device", None)
+                if dev is None:
+                    prm = next(sw.parameters(), None)
+                    dev = prm.device if prm is not None else "cpu"
+                x = torch.Tensor([current_s]).to(dev)
+                x = x.reshape(x.size(0), -1)
+                with torch.no_grad():
+                    out = sw(x)[0]
+                new_v = torch.reshape(out, (len(self.humans), 2)).tolist()
+            else:
+                new_v = sw(current_s)                   # SGANWorld-style callable -> [N,2]
         gv = torch.tensor(np.asarray(new_v, np.float64).reshape(1, len(self.humans), 2), dtype=torch.float64,
                           device=v.device)
         self._pending_given = gv

@@ -134,3 +134,34 @@ def test_attention_world_kernel_matches_torch_module(N):
             with torch.no_grad():
                 ref = world(x[e:e + 1, :n].reshape(1, -1)).view(n, 2).double()
             assert float((part[e, :n] - ref).abs().max()) <= 1e-5, e
+
+
+def test_e1_model_crowd_sim_steps_with_a_torch_world_module():
+    """The reference's E = 1 surface (model_crowd_sim.py:398-417): `env.sim_world = MlpWorld(...)` -- a plain nn.Module,
+    not an SGANWorld -- gets the scene as one float32 row and its output row moves the humans."""
+    import torch
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.envs import ModelCrowdSim
+    from modelcrowdnav_amd.envs.policy.policy_factory import policy_factory
+    from modelcrowdnav_amd.envs.utils.action import ActionXY
+    from modelcrowdnav_amd.envs.utils.robot import Robot
+    from modelcrowdnav_amd.policy.world_model import MlpWorld
+    cfg = configs.env_config()
+    env = ModelCrowdSim()
+    env.configure(cfg)
+    robot = Robot(cfg, "robot")
+    pol = policy_factory["orca"]()
+    pol.multiagent_training = True
+    robot.set_policy(pol)
+    env.set_robot(robot)
+    ob = env.reset("test", 3)
+    N = len(ob)
+    torch.manual_seed(1)
+    world = MlpWorld(N).eval()
+    env.sim_world = world
+    before = np.array([[h.px, h.py, h.vx, h.vy] for h in env.humans])
+    with torch.no_grad():
+        want = world(torch.Tensor([before.tolist()]).reshape(1, -1))[0].reshape(N, 2).double().numpy()
+    ob2, reward, done, info = env.step(ActionXY(0.0, 0.0))
+    after = np.array([[h.px, h.py, h.vx, h.vy] for h in env.humans])
+    assert np.allclose(after[:, 2:4], want, atol=0) and np.allclose(after[:, 0:2], before[:, 0:2] + want * env.time_step, atol=1e-15)

@@ -27,6 +27,7 @@ int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double
                   double *action_out, int E, int N, hipStream_t stream);
 #ifdef MCN_DIAG
 int read_pool_clock(void *dst, size_t bytes);
+int read_sarl_phases(void *dst, size_t bytes, int reset);
 #endif
 int launch_sgan(const mcn_sgan_net *net, double *hist, int push_slot, int oldest, const double *cur_pos,
                 const float *noise, const int32_t *hcount, void *workspace, double *out_vel, float *out_rel,
@@ -361,6 +362,8 @@ int mcn_sgan_step(const mcn_sgan_net *net, double *hist, int32_t push_slot, int3
 #ifdef MCN_DIAG
 // diagnostic build only: [workgroup][4] = s_memtime, s_memrealtime before / after the SGAN pool kernel's unit loop
 int mcn_debug_pool_clock(void *dst_host, int64_t bytes) { return mcn::read_pool_clock(dst_host, (size_t)bytes); }
+// diagnostic build only: [resident wavefront][16] shader cycles per phase of sarl_value_kernel (tools/sarl_phases.py)
+int mcn_debug_sarl_phases(void *dst_host, int64_t bytes, int32_t reset) { return mcn::read_sarl_phases(dst_host, (size_t)bytes, reset); }
 // diagnostic build only: copies the rollout kernel's time stamps to host memory, returns the number of 8-byte words
 int mcn_debug_stamps(void *dst_host, int64_t bytes) { return mcn::read_stamps(dst_host, (size_t)bytes); }
 // per-wavefront counts of the data-dependent paths taken: [wave][4] = 3-D LP, restarts, overlap sqrt, goal sqrt

@@ -83,6 +83,33 @@ struct SarlParams {
 
 __device__ __forceinline__ double norm2d(double x0, double x1) { return sqrt(fma(x1, x1, x0 * x0)); }
 
+// Diagnostic build only (tools/sarl_phases.py): shader cycles each resident wavefront spends in each phase of a tile,
+// summed over the tiles it walks.  [wavefront][16]: see PHASES in the tool.
+#ifdef MCN_DIAG
+__device__ unsigned long long g_sarl_phase[2048 * 16];
+#define SARL_T0() unsigned long long sp_t_ = __builtin_amdgcn_s_memtime()
+#define SARL_PHASE(k_)                                                                                          \
+    do {                                                                                                        \
+        const unsigned long long n_ = __builtin_amdgcn_s_memtime();                                             \
+        const int w_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                                     \
+        if ((threadIdx.x & 63) == 0 && w_ < 2048) g_sarl_phase[w_ * 16 + (k_)] += n_ - sp_t_;                   \
+        sp_t_ = n_;                                                                                             \
+    } while (0)
+int read_sarl_phases(void *dst, size_t bytes, int reset)
+{
+    if (bytes > sizeof(g_sarl_phase)) bytes = sizeof(g_sarl_phase);
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_sarl_phase), bytes) != hipSuccess) return -1;
+    if (reset) {
+        void *p_ = nullptr;
+        if (hipGetSymbolAddress(&p_, HIP_SYMBOL(g_sarl_phase)) != hipSuccess || hipMemset(p_, 0, sizeof(g_sarl_phase)) != hipSuccess) return -1;
+    }
+    return (int)(bytes / 8);
+}
+#else
+#define SARL_T0()
+#define SARL_PHASE(k_)
+#endif
+
 constexpr int kSarlWaves = kStageThreads / 64;     // 8 wavefronts share one LDS weight stage (2 per SIMD)
 
 __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl_value_kernel(const SarlParams p)
@@ -104,6 +131,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
     // this wavefront's workspace slot: by resident wavefront (persistent grid), reused for every tile it walks over
     float4 *const ws = p.workspace + ((long)blockIdx.x * kSarlWaves + wave) * (long)N * T100 * 64;
     const long pair0 = (grp * kSarlWaves + wave) * 16;
+    SARL_T0();
     // no early exit: every wavefront of the workgroup takes part in the weight staging barriers
     long pair = pair0 + j;
     const bool valid = pair < npairs;
@@ -147,6 +175,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
 #pragma unroll
     for (int t = 0; t < T100; ++t) gsum[t] = (f32x4){0, 0, 0, 0};
     double dmin = INFINITY;
+    SARL_PHASE(0);                      // tile set-up: robot state, self features
     for (int i = 0; i < N; ++i) {
         // per-pass opaque copy of the thread id: the staging addresses of this pass's layers are re-derived here
         // (a few integer instructions) instead of being hoisted out of the loop as ~30 live 64-bit values
@@ -182,15 +211,19 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
 #pragma unroll
         for (int r = 0; r < 4; ++r)      // register r of lane group q carries feature 4q + r
             x[0][r] = q == 0 ? feat[r] : (q == 1 ? feat[4 + r] : (q == 2 ? feat[8 + r] : feat[12 + r]));
+        SARL_PHASE(1);                  // per human: state loads, float64 distance, rotated features
         f32x4 h1[T150];
         dense_staged<T13, T150, true, false>(x, nullptr, h1, p.f.w_m1a, p.f.b_m1a, S, lane);
+        SARL_PHASE(2);                  // mlp1.0
         f32x4 h2[T100];
         dense_staged<T150, T100, true, false, 2>(h1, nullptr, h2, p.f.w_m1b, p.f.b_m1b, S, lane);
+        SARL_PHASE(3);                  // mlp1.2
 #pragma unroll
         for (int t = 0; t < T100; ++t) {
             ws[(i * T100 + t) * 64 + lane] = make_float4(h2[t][0], h2[t][1], h2[t][2], h2[t][3]);
             if (i < ne) gsum[t] += h2[t];
         }
+        SARL_PHASE(4);                  // workspace store, global-state sum
     }
     // reward ladder of MultiHumanRL.compute_reward with its hard-coded constants
     const bool reach = norm2d(npx - rg.x, npy - rg.y) < ra.x;
@@ -210,6 +243,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
         for (int r = 0; r < 4; ++r) gsum[t][r] = gsum[t][r] / fn;
     f32x4 gat[T100];
     dense_staged<T100, T100, false, false, 1>(gsum, nullptr, gat, p.f.w_atg, p.f.b_ata, S, lane);
+    SARL_PHASE(5);                      // reward ladder, mean, global half of attention.0
 
     // ---- pass 2: attention score, mlp2, pooling ----
     // mlp2's last layer is linear (sarl.py:31, cadrl.py:11-19: no ReLU after the last Linear) and the attention
@@ -230,23 +264,30 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
             const float4 v = ws[(i * T100 + t) * 64 + lane];
             h2[t] = (f32x4){v.x, v.y, v.z, v.w};
         }
+        SARL_PHASE(6);                  // workspace load
         f32x4 a1[T100];
         dense_staged<T100, T100, true, true, 1>(h2, gat, a1, p.f.w_ata, nullptr, S, lane);
+        SARL_PHASE(7);                  // attention.0
         f32x4 a2[T100];
         dense_staged<T100, T100, true, false, 1>(a1, nullptr, a2, p.f.w_atb, p.f.b_atb, S, lane);
+        SARL_PHASE(8);                  // attention.2
         f32x4 sc[T1];
         dense_staged<T100, T1, false, false, 1>(a2, nullptr, sc, p.f.w_atc, p.f.b_atc, S, lane);
+        SARL_PHASE(9);                  // attention.4
         // score of pair j sits in lane j (q = 0), register 0; broadcast to the pair's four lanes
         const float s = __shfl(sc[0][0], j);
         const float es = (s != 0.0f && i < ne) ? expf(s) : 0.0f;   // exp(s) * (s != 0), sarl.py:52; absent: 0
         if (p.attention && valid && q == 0) p.attention[pair * N + i] = es;   // normalised by the host view
         denom += es;
+        SARL_PHASE(10);                 // exp, attention output
         f32x4 m1[T100];
         dense_staged<T100, T100, true, false, 1>(h2, nullptr, m1, p.f.w_m2a, p.f.b_m2a, S, lane);
+        SARL_PHASE(11);                 // mlp2.0
 #pragma unroll
         for (int t = 0; t < T100; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) racc[t][r] = i < ne ? racc[t][r] + es * m1[t][r] : racc[t][r];
+        SARL_PHASE(12);                 // weighted accumulation
     }
 
     // ---- tail: mlp3 on [self(6), pooled(50)] ----
@@ -268,6 +309,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
         const float s1 = q == 0 ? f_vx : (q == 1 ? f_vy : 0.0f);
         jin[T50] = (f32x4){s0, s1, 0.0f, 0.0f};
     }
+    SARL_PHASE(13);                     // normalise, mlp2.2, self tile
     f32x4 v1[T150];
     dense_staged<T56, T150, true, false, 2, 1>(jin, nullptr, v1, p.f.w_m3a, p.f.b_m3a, S, lane);
     f32x4 v2[T100];
@@ -283,6 +325,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
     if (p.attention && valid && q == 0) {
         for (int i = 0; i < N; ++i) p.attention[pair * N + i] /= denom;
     }
+    SARL_PHASE(14);                     // mlp3, value store
   }
 }
 

@@ -630,7 +630,9 @@ int launch_env_step(const StepParams &p_in, hipStream_t stream)
     if ((p.pair_stream > 0 || (p.pair_stream < 0 && waves_total > 4096)) && launch_env_pair(p, stream))
         return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
     // small batches: one wavefront per workgroup so the grid covers as many CUs as possible
-    const bool one_wave = p.step_block > 0 ? p.step_block == 64 : waves_total <= 4096;
+    // (crowds of 9-10: the one-wavefront workgroups with the cooperative 3-D LP stay ahead longer -- 10 humans,
+    //  32 768 envs 63.6 vs 67.1 us, 65 536 envs 105 vs 110, 2^18 envs 391 vs 307; 7 humans cross at ~24 k envs)
+    const bool one_wave = p.step_block > 0 ? p.step_block == 64 : waves_total <= (nc >= 8 ? 12288 : 4096);
     if (one_wave) dispatch<64>(p, waves_total, stream);
     else                     dispatch<256>(p, (waves_total + 3) / 4, stream);
     if (p.lp3_defer) launch_env_lp3(p, stream);

@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--no-hh", action="store_true", help="no human-human overlap count (ModelCrowdSim.step does not count)")
     ap.add_argument("--pair-stream", type=int, default=-1, help="mcn_tuning.pair_stream")
     ap.add_argument("--lp3-defer", type=int, default=-1, help="mcn_tuning.lp3_defer")
+    ap.add_argument("--step-block", type=int, default=-1, help="mcn_tuning.step_block (64 / 256)")
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--sarl", action="store_true")
     ap.add_argument("--rollout", type=int, default=0, help="time mcn_env_rollout with this many steps per launch")
@@ -70,6 +71,9 @@ def main():
         return
     dev = torch.device("cuda", 0)
     N = a.humans
+    if a.step_block > 0:
+        from modelcrowdnav_amd import _hip
+        _hip.set_tuning(step_block=a.step_block)
     if a.lp3_defer >= 0:                       # before the env allocates (or skips) its 3-D-LP queue
         from modelcrowdnav_amd import _hip
         _hip.set_tuning(lp3_defer=a.lp3_defer)

@@ -430,6 +430,16 @@ def extra_configs(device):
                 "ms_per_step": round(ms10, 5), "env_steps_per_sec": round(E / ms10 * 1e3, 1),
                 "roofline": roofline_entry(E, N, ms10),
                 "roofline_valu": valu_roofline(E, N, ms10, 1, rollout=False)})
+    del env
+    # ---- config 5's WHOLE batch on one GPU: 32 768 envs x 10 humans (what a node with one MI355X would run) ----
+    E = 32768
+    env, _ = build_env(E, N, 0, device)
+    acts10 = make_actions(64, E, E, 0, device)
+    ms10w, _best = time_kernel_events(env, acts10, 100)
+    out.append({"config": "32 768 envs x 10 humans on ONE GPU (BASELINE configs[4]'s whole batch), ORCA humans, random robot "
+                          "actions, one mcn_env_step launch per step",
+                "ms_per_step": round(ms10w, 5), "env_steps_per_sec": round(E / ms10w * 1e3, 1),
+                "roofline": roofline_entry(E, N, ms10w)})
     return out
 
 

@@ -282,12 +282,15 @@ int mcn_sarl_lookahead_env(const mcn_sarl_net *net, const mcn_env_state *st, con
  * goal) or every value is NaN (best[e] < 0 with best_val = -inf: "Value network is not well trained", the caller's
  * error).  next_hpos / next_hvel / rewards: all NULL (mcn_sarl_lookahead's propagate + compute_reward) or all set
  * (mcn_sarl_lookahead_env's `query_env` form).  action_out: [E][2] device out.  Everything else as above.
+ * epsilon > 0 (phase 'train', multi_human_rl.py:27-29): each env not on its goal independently takes, with
+ * probability epsilon, a uniformly drawn row of `actions` instead of the best one (best[e] = -2); the draws are a
+ * counter-based function of (seed, env), so pass a fresh seed per call.  epsilon = 0: greedy, seed ignored.
  */
 int mcn_sarl_predict(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int32_t A,
                      double time_step, double gamma_pow, int32_t kinematics, void *workspace,
                      double *values, int32_t *best, double *best_val, float *attention,
                      const double *next_hpos, const double *next_hvel, const double *rewards,
-                     double *action_out, int32_t E, int32_t N, void *stream);
+                     double *action_out, double epsilon, uint64_t seed, int32_t E, int32_t N, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Social-GAN one-step world model (crowd_nav/policy/world_model.py:134-268, sgan/models.py:501-553).

@@ -134,7 +134,7 @@ def _load():
                                            _vp, _vp, _vp, _i, _i, _vp]
     lib.mcn_sarl_lookahead_env.restype = C.c_int
     lib.mcn_sarl_predict.argtypes = [_vp, C.POINTER(EnvState), _vp, _i, _d, _d, _i, _vp, _vp, _vp, _vp, _vp,
-                                     _vp, _vp, _vp, _vp, _i, _i, _vp]
+                                     _vp, _vp, _vp, _vp, _d, C.c_uint64, _i, _i, _vp]
     lib.mcn_sarl_predict.restype = C.c_int
     lib.mcn_mlp_world_step.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _vp]
     lib.mcn_mlp_world_step.restype = C.c_int

@@ -24,7 +24,7 @@ long attn_world_workspace_float4s(int E, int N);
 int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int A, double dt,
                   double gamma_pow, int kinematics, void *workspace, double *values, int32_t *best, double *best_val,
                   float *attention, const double *next_hpos, const double *next_hvel, const double *reward_in,
-                  double *action_out, int E, int N, hipStream_t stream);
+                  double *action_out, double epsilon, unsigned long long seed, int E, int N, hipStream_t stream);
 #ifdef MCN_DIAG
 int read_pool_clock(void *dst, size_t bytes);
 int read_sarl_phases(void *dst, size_t bytes, int reset);
@@ -262,10 +262,11 @@ static int sarl_lookahead_impl(const mcn_sarl_net *net, const mcn_env_state *st,
                                double time_step, double gamma_pow, int32_t kinematics, void *workspace,
                                double *values, int32_t *best, double *best_val, float *attention,
                                const double *next_hpos, const double *next_hvel, const double *rewards,
-                               double *action_out, int32_t E, int32_t N, void *stream)
+                               double *action_out, double epsilon, uint64_t seed, int32_t E, int32_t N, void *stream)
 {
     if (!net || !st || !actions || !workspace || !values) return MCN_EINVAL;
     if (action_out && !best) return MCN_EINVAL;
+    if (!(epsilon >= 0.0 && epsilon <= 1.0)) return MCN_EINVAL;
     if (E <= 0 || N <= 0 || N > MCN_MAX_HUMANS || A <= 0) return MCN_EINVAL;
     if (best && !best_val) return MCN_EINVAL;
     if (!st->hpos || !st->hvel || !st->hrad || !st->rpos || !st->rgoal || !st->rrad || !st->rvpref) return MCN_EINVAL;
@@ -276,7 +277,8 @@ static int sarl_lookahead_impl(const mcn_sarl_net *net, const mcn_env_state *st,
         if (!fp[k]) return MCN_EINVAL;
     if (!(time_step > 0)) return MCN_EINVAL;
     return mcn::launch_sarl_c(net, st, actions, A, time_step, gamma_pow, kinematics, workspace, values, best,
-                              best_val, attention, next_hpos, next_hvel, rewards, action_out, E, N, (hipStream_t)stream);
+                              best_val, attention, next_hpos, next_hvel, rewards, action_out, epsilon,
+                              (unsigned long long)seed, E, N, (hipStream_t)stream);
 }
 
 int mcn_sarl_lookahead(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int32_t A,
@@ -285,7 +287,7 @@ int mcn_sarl_lookahead(const mcn_sarl_net *net, const mcn_env_state *st, const d
                        int32_t E, int32_t N, void *stream)
 {
     return sarl_lookahead_impl(net, st, actions, A, time_step, gamma_pow, kinematics, workspace, values, best, best_val,
-                               attention, nullptr, nullptr, nullptr, nullptr, E, N, stream);
+                               attention, nullptr, nullptr, nullptr, nullptr, 0.0, 0, E, N, stream);
 }
 
 int mcn_sarl_lookahead_env(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int32_t A,
@@ -296,19 +298,19 @@ int mcn_sarl_lookahead_env(const mcn_sarl_net *net, const mcn_env_state *st, con
 {
     if (!next_hpos || !next_hvel || !rewards) return MCN_EINVAL;
     return sarl_lookahead_impl(net, st, actions, A, time_step, gamma_pow, kinematics, workspace, values, best, best_val,
-                               attention, next_hpos, next_hvel, rewards, nullptr, E, N, stream);
+                               attention, next_hpos, next_hvel, rewards, nullptr, 0.0, 0, E, N, stream);
 }
 
 int mcn_sarl_predict(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int32_t A,
                      double time_step, double gamma_pow, int32_t kinematics, void *workspace,
                      double *values, int32_t *best, double *best_val, float *attention,
                      const double *next_hpos, const double *next_hvel, const double *rewards,
-                     double *action_out, int32_t E, int32_t N, void *stream)
+                     double *action_out, double epsilon, uint64_t seed, int32_t E, int32_t N, void *stream)
 {
     if (!best || !action_out) return MCN_EINVAL;
     if ((next_hpos == nullptr) != (rewards == nullptr)) return MCN_EINVAL;
     return sarl_lookahead_impl(net, st, actions, A, time_step, gamma_pow, kinematics, workspace, values, best, best_val,
-                               attention, next_hpos, next_hvel, rewards, action_out, E, N, stream);
+                               attention, next_hpos, next_hvel, rewards, action_out, epsilon, seed, E, N, stream);
 }
 
 int mcn_mlp_world_step(const mcn_mlp_world_net *net, const double *hpos, const double *hvel, double *out_vel,

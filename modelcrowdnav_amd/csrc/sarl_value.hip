@@ -335,7 +335,8 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
 __global__ __launch_bounds__(64) void sarl_argmax_kernel(const double *__restrict__ values, const double *rpos,
                                                        const double *rgoal, const double *rrad, int E, int A,
                                                        int32_t *__restrict__ best, double *__restrict__ best_val,
-                                                       const double *__restrict__ actions, double *__restrict__ action_out)
+                                                       const double *__restrict__ actions, double *__restrict__ action_out,
+                                                       double epsilon, unsigned long long seed)
 {
     const int e = blockIdx.x;
     const int lane = threadIdx.x;
@@ -355,13 +356,30 @@ __global__ __launch_bounds__(64) void sarl_argmax_kernel(const double *__restric
         const double2 rg = reinterpret_cast<const double2 *>(rgoal)[e];
         // numpy norm((py - gy, px - gx)): dot = fma(x1, x1, x0 * x0) with x0 = py-gy, x1 = px-gx
         const bool reached = norm2d(rp.y - rg.y, rp.x - rg.x) < rrad[e];
-        best[e] = reached ? -1 : bi;
+        // epsilon-greedy (multi_human_rl.py:27-29, phase 'train'): with probability epsilon the env takes a uniformly
+        // drawn table row instead (best = -2); a robot on its goal returns before the draw (:22-23).  Counter-based
+        // stream: two 64-bit mixes of (seed, env) -- the caller passes a fresh seed per call.
+        int choice = bi;
+        bool explore = false;
+        if (epsilon > 0.0 && !reached) {
+            auto mix = [](unsigned long long z) {                      // splitmix64 finaliser
+                z += 0x9E3779B97F4A7C15ull;
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                return z ^ (z >> 31);
+            };
+            const unsigned long long r1 = mix(seed ^ mix((unsigned long long)e));
+            const unsigned long long r2 = mix(r1);
+            explore = (double)(r1 >> 11) * (1.0 / 9007199254740992.0) < epsilon;
+            if (explore) choice = (int)(((r2 >> 32) * (unsigned long long)A) >> 32);
+        }
+        best[e] = reached ? -1 : (explore ? -2 : bi);
         best_val[e] = bv;
         if (action_out) {
             // what MultiHumanRL.predict returns: the table row of the best value, the zero action on the goal
             // (multi_human_rl.py:22-23) -- and also when every value is NaN (bi < 0: the host raises, as the reference)
-            const bool zero = reached || bi < 0;
-            const double2 act = reinterpret_cast<const double2 *>(actions)[zero ? 0 : bi];
+            const bool zero = reached || choice < 0;
+            const double2 act = reinterpret_cast<const double2 *>(actions)[zero ? 0 : choice];
             reinterpret_cast<double2 *>(action_out)[e] = zero ? make_double2(0.0, 0.0) : act;
         }
     }
@@ -373,7 +391,8 @@ __global__ __launch_bounds__(64) void sarl_argmax_kernel(const double *__restric
 #endif
 constexpr int kSarlMaxBlocks = MCN_SARL_MAX_BLOCKS;     // A/B: a huge value = one workgroup per 4-tile group, workspace by tile
 
-int launch_sarl(SarlParams &p, int32_t *best, double *best_val, double *action_out, hipStream_t stream)
+int launch_sarl(SarlParams &p, int32_t *best, double *best_val, double *action_out, double epsilon,
+                unsigned long long seed, hipStream_t stream)
 {
     const long npairs = (long)p.E * p.A;
     const long waves = (npairs + 15) / 16;
@@ -382,7 +401,7 @@ int launch_sarl(SarlParams &p, int32_t *best, double *best_val, double *action_o
     hipLaunchKernelGGL(sarl_value_kernel, dim3(blocks), dim3(kSarlWaves * 64), 0, stream, p);
     if (best) {
         hipLaunchKernelGGL(sarl_argmax_kernel, dim3(p.E), dim3(64), 0, stream, p.values, p.rpos, p.rgoal, p.rrad,
-                           p.E, p.A, best, best_val, p.actions, action_out);
+                           p.E, p.A, best, best_val, p.actions, action_out, epsilon, seed);
     }
     return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
 }
@@ -390,7 +409,7 @@ int launch_sarl(SarlParams &p, int32_t *best, double *best_val, double *action_o
 int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double *actions, int A, double dt,
                   double gamma_pow, int kinematics, void *workspace, double *values, int32_t *best, double *best_val,
                   float *attention, const double *next_hpos, const double *next_hvel, const double *reward_in,
-                  double *action_out, int E, int N, hipStream_t stream)
+                  double *action_out, double epsilon, unsigned long long seed, int E, int N, hipStream_t stream)
 {
     SarlParams p;
     const float4 *const *src = reinterpret_cast<const float4 *const *>(net);
@@ -403,7 +422,7 @@ int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double
     p.actions = actions; p.workspace = reinterpret_cast<float4 *>(workspace);
     p.values = values; p.attention = attention;
     p.E = E; p.N = N; p.A = A; p.kinematics = kinematics; p.dt = dt; p.gamma_pow = gamma_pow;
-    return launch_sarl(p, best, best_val, action_out, stream);
+    return launch_sarl(p, best, best_val, action_out, epsilon, seed, stream);
 }
 
 long sarl_workspace_float4s(int E, int N, int A)

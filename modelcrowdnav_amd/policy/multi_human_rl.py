@@ -36,7 +36,7 @@ class MultiHumanRL(CADRL):
     def _packed(self, dev):
         raise NotImplementedError
 
-    def _lookahead(self, st, E, N, dev, want_attention=False, env_next=None):
+    def _lookahead(self, st, E, N, dev, want_attention=False, env_next=None, epsilon=0.0):
         """Launch mcn_sarl_predict on an EnvState struct; returns (values[E,A], best[E], best_val[E], att); the chosen
         actions [E,2] (table row of `best`, zero where the robot stands on its goal) are left in self._bufs["action"].
         env_next = (next_hpos [E,N,2], next_hvel [E,N,2], rewards [E,A]): the `query_env` form -- the env's
@@ -68,6 +68,10 @@ class MultiHumanRL(CADRL):
                                        _hip.ptr(b["ws"]), _hip.ptr(b["values"]), _hip.ptr(b["best"]),
                                        _hip.ptr(b["best_val"]), _hip.ptr(b["att"]) if want_attention else None,
                                        _hip.ptr(npos), _hip.ptr(nvel), _hip.ptr(rew), _hip.ptr(b["action"]),
+                                       float(epsilon),
+                                       # a fresh 63-bit seed per call from torch's host generator (no device launch):
+                                       # torch.manual_seed() makes training rollouts reproducible
+                                       int(torch.randint(0, 2 ** 62, (1,)).item()) if epsilon > 0 else 0,
                                        E, N, _hip.stream_ptr(dev))
         _hip.check(rc, "mcn_sarl_predict")
         return b["values"], b["best"], b["best_val"], b["att"]
@@ -205,18 +209,11 @@ class MultiHumanRL(CADRL):
             if self._bufs.get("table") is None:
                 self._bufs["table"] = torch.from_numpy(np.ascontiguousarray(self._action_table)).to(dev)
             env_next = self._query_env(env)
-        values, best, best_val, _ = self._lookahead(st, env.num_envs, env._alloc_N, dev, env_next=env_next)
-        table = self._bufs["table"]
-        eps = float(getattr(self, "epsilon", 0) or 0)
-        if self.phase == "train" and eps > 0:
-            E = env.num_envs
-            explore = (torch.rand(E, device=dev) < eps) & (best >= 0)        # a robot on its goal returns before the draw
-            ridx = torch.randint(0, table.shape[0], (E,), device=dev, dtype=best.dtype)
-            best = torch.where(explore, torch.full_like(best, -2), best)
-            idx = torch.where(explore, ridx, best.clamp(min=0)).long()
-            actions = table[idx] * (best != -1).unsqueeze(1).to(table.dtype)
-        else:
-            actions = self._bufs["action"]          # written by the look-ahead's argmax kernel: no torch launches
+        eps = float(getattr(self, "epsilon", 0) or 0) if self.phase == "train" else 0.0
+        # epsilon-greedy happens inside the look-ahead's argmax kernel (one draw per env per step from a counter-based
+        # stream seeded from torch's generator): best == -2 marks the envs that explored
+        values, best, best_val, _ = self._lookahead(st, env.num_envs, env._alloc_N, dev, env_next=env_next, epsilon=eps)
+        actions = self._bufs["action"]              # written by the argmax kernel: no torch launches
         if want_values:
             return actions, best, values
         return actions, best

@@ -147,13 +147,13 @@ def test_epsilon_greedy_in_train_phase():
     st = H.random_state(rng, E, N)
     st.rgx[0], st.rgy[0] = st.rpx[0] + 0.05, st.rpy[0] - 0.05        # env 0: robot already at its goal
     H.upload(env, st)
-    greedy_a, greedy_b = pol.predict_batch(env)
+    greedy_a, greedy_b = (x.clone() for x in pol.predict_batch(env))     # the outputs are the policy's own buffers
     pol.set_epsilon(1.0)
     a_test, b_test = pol.predict_batch(env)                          # phase 'test': epsilon is not looked at
     assert torch.equal(b_test, greedy_b) and torch.equal(a_test, greedy_a)
     pol.set_phase("train")
     torch.manual_seed(5)
-    a1, b1 = pol.predict_batch(env)
+    a1, b1 = (x.clone() for x in pol.predict_batch(env))
     assert int(b1[0]) == -1 and tuple(a1[0].tolist()) == (0.0, 0.0)
     moving = greedy_b >= 0
     assert bool((b1[moving] == -2).all())
@@ -165,7 +165,7 @@ def test_epsilon_greedy_in_train_phase():
     assert int((counts > 0).sum()) >= 75 and float(counts.max()) < 0.05 * float(moving.sum())
     assert float((a1[moving] != greedy_a[moving]).any(1).float().mean()) > 0.9
     pol.set_epsilon(0.25)
-    a2, b2 = pol.predict_batch(env)
+    a2, b2 = (x.clone() for x in pol.predict_batch(env))
     frac = float((b2[moving] == -2).float().mean())
     assert 0.2 < frac < 0.3
     keep = moving & (b2 != -2)
@@ -173,6 +173,14 @@ def test_epsilon_greedy_in_train_phase():
     pol.set_epsilon(0.0)
     a3, b3 = pol.predict_batch(env)
     assert torch.equal(b3, greedy_b) and torch.equal(a3, greedy_a)
+    # reproducible under torch.manual_seed, different from call to call
+    pol.set_epsilon(0.5)
+    torch.manual_seed(9)
+    x1 = pol.predict_batch(env)[0].clone()
+    x2 = pol.predict_batch(env)[0].clone()
+    torch.manual_seed(9)
+    y1 = pol.predict_batch(env)[0].clone()
+    assert torch.equal(x1, y1) and not torch.equal(x1, x2)
 
 
 def test_rewards_are_float64_exact():

@@ -101,3 +101,43 @@ def test_roofline_entries_carry_traffic_and_valu():
     p = bench.valu_roofline(1 << 20, 5, 0.13, 1, rollout=False, given=True)
     assert f["kernel"].startswith("mcn::env_step_kernel") and p["kernel"].startswith("mcn::env_pair_kernel")
     assert bench.valu_roofline(777, 5, 1.0, 1, rollout=False) is None
+
+
+def test_pmc_summariser_classifies_by_template_arguments(tmp_path):
+    """tools/pmc_summary.py on a synthetic pair of counter passes: the streaming pair kernel (whose name carries no MODE
+    argument) is given-velocity traffic with the 566-B accounting, `env_step_kernel<256, 5, 0, 0, 2>` (HH = 2, MODE = 0)
+    is fused-ORCA traffic, and each launch is matched to the batch size its grid covers."""
+    import csv
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench
+    import pmc_summary
+    hdr = ["Kernel_Name", "Grid_Size", "Workgroup_Size", "Counter_Name", "Counter_Value"]
+    rows = [("void mcn::env_pair_kernel<5, true>(mcn::StepParams)", 5592576, 256),
+            ("void mcn::env_step_kernel<256, 5, 0, 0, 2>(mcn::StepParams)", 5592576, 256),
+            ("void mcn::env_step_kernel<64, 0, 0, 2, 0>(mcn::StepParams)", 21888, 64),
+            ("void mcn::env_step_quad_kernel<5, 0, false>(mcn::StepParams)", 87424, 64),
+            ("void at::native::something(int)", 1024, 256)]
+    for ctr, d, val in (("FETCH_SIZE", "f", 1000.0), ("WRITE_SIZE", "w", 500.0)):
+        os.makedirs(tmp_path / d)
+        with open(tmp_path / d / "x_counter_collection.csv", "w", newline="") as fh:
+            wr = csv.writer(fh)
+            wr.writerow(hdr)
+            for name, grid, wg in rows:
+                for rep in range(2):
+                    wr.writerow([name, grid, wg, ctr, val + rep])
+    alg = lambda n, given: bench.pairwise_bytes_per_env_step(n) if given else bench.algorithmic_bytes_per_env_step(n)
+    out = pmc_summary.summarise((str(tmp_path / "f"), str(tmp_path / "w"), 5, [4096, 1048576], 1), alg)
+    by = {k["kernel"]: k for k in out}
+    assert len(out) == 4                                                     # the torch kernel is dropped
+    pair = by["mcn::env_pair_kernel<5, true>"]
+    assert (pair["family"], pair["mode"], pair["humans"], pair["envs"]) == ("env_pair_kernel", "given", 5, 1048576)
+    assert pair["algorithmic_bytes_per_launch"] == 566 * 1048576
+    fused = by["mcn::env_step_kernel<256, 5, 0, 0, 2>"]
+    assert (fused["family"], fused["mode"], fused["envs"]) == ("env_step_kernel", "orca", 1048576)
+    assert fused["algorithmic_bytes_per_launch"] == 622 * 1048576
+    small = by["mcn::env_step_kernel<64, 0, 0, 2, 0>"]
+    assert (small["mode"], small["humans"], small["envs"]) == ("given", 5, 4096)
+    assert by["mcn::env_step_quad_kernel<5, 0, false>"]["envs"] == 4096
+    # reads doubled (gfx950 FETCH_SIZE), writes as they are; KB -> bytes; mean of the two launches
+    assert pair["traffic_bytes_per_launch"] == int(2 * 1000.5 * 1024 + 500.5 * 1024)

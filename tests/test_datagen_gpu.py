@@ -36,12 +36,12 @@ RUNS = [("il_freeze", dict(imitation_learning=True, add_sim=False, random_epi=Tr
         ("ragged_sgan", dict(add_sim=True, random_epi=True, updateMemory=False, sgan_world=True), 15, 7)]
 
 
-def _setup(g, name, E, n_world=5):
+def _setup(g, name, E, n_world=5, hip_world=False):
     import torch
     from modelcrowdnav_amd import configs
     from modelcrowdnav_amd.envs import VecModelCrowdSim
     from modelcrowdnav_amd.policy.sarl import SARL
-    from modelcrowdnav_amd.policy.world_model import MlpWorld, VecTorchWorld
+    from modelcrowdnav_amd.policy.world_model import MlpWorld, VecMlpWorld, VecTorchWorld, vec_world
     from modelcrowdnav_amd.utils.memory import ReplayMemory
     from modelcrowdnav_amd.utils.datagen import VecDataGen
     dev = torch.device("cuda", 0)
@@ -57,7 +57,8 @@ def _setup(g, name, E, n_world=5):
     pref = name + "_world__"
     world.load_state_dict({k[len(pref):].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith(pref)})
     world.eval().to(dev)
-    env.sim_world = VecTorchWorld(world, env)
+    env.sim_world = vec_world(world, env) if hip_world else VecTorchWorld(world, env)
+    assert not hip_world or isinstance(env.sim_world, VecMlpWorld)          # mcn_mlp_world_step, not torch
     memory = ReplayMemory(100000)
     dg = VecDataGen(memory, env.robot, env, pol)
     raw = []
@@ -84,12 +85,17 @@ def _setup(g, name, E, n_world=5):
 
 @pytest.mark.parametrize("name,kw,seed,num", RUNS)
 @pytest.mark.parametrize("E", [4, 16])
-def test_explore_in_mix_matches_reference(name, kw, seed, num, E, golden_dir):
+@pytest.mark.parametrize("hip_world", [False, True], ids=["torch-world", "hip-world"])
+def test_explore_in_mix_matches_reference(name, kw, seed, num, E, hip_world, golden_dir):
+    """`hip-world`: the imagined steps come from world_mlp.hip (mcn_mlp_world_step) instead of the torch module, so the
+    kernel is held to the real reference's recorded outputs, not only to this repo's module."""
     g = np.load(os.path.join(golden_dir, "g8_datagen.npz"))
     kw = dict(kw)
     sgan = kw.pop("sgan_world", False)
+    if hip_world and (sgan or not kw.get("add_sim", True)):
+        pytest.skip("no MlpWorld step in this run")
     dg, memory = _setup(g, ("ragged_eval" if name.startswith("ragged") else "il_freeze") if sgan else name, E,
-                        4 if kw.get("replace_robot") else 5)
+                        4 if kw.get("replace_robot") else 5, hip_world=hip_world)
     if sgan:
         import torch
         from modelcrowdnav_amd.policy.world_model import VecSGANWorld, generator_from_arrays

@@ -17,6 +17,8 @@
               and value targets                                                (explorer.py:153-186)
   g10_trainer Trainer.optimize_batch / optimize_epoch (SGD momentum 0.9, MSE) on a seeded ValueNetwork and memory:
               weights before / after, losses                                   (trainer.py:19-82)
+  g13_world   MlpWorld (eval mode) and AttentionWorld forward on seeded scenes with seeded default-init weights
+                                                                      (world_model.py:22-106)
   g8_datagen  DataGen.gen_data_from_explore_in_mix on a synthetic recorded set: replay-then-freeze and
               replay-then-imagine (MlpWorld) samples, memory contents in IL and RL mode
                                                                       (datagen.py:379-543)
@@ -493,4 +495,38 @@ def g10_trainer():
     print("g10_trainer: %d arrays" % len(rec))
 
 
-FAMILIES = {"g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}
+def g13_world():
+    """The two world-model modules of crowd_nav/policy/world_model.py:22-106 evaluated by the reference itself: input
+    rows are [px, py, vx, vy] per pedestrian (datagen.py:505-510 builds them that way), outputs the next velocities.
+    MlpWorld runs in eval mode (its Dropout layers are the identity, as when the training script imagines)."""
+    from crowd_sim.envs.utils.state import JointState  # noqa: F401
+    from crowd_nav.policy.world_model import MlpWorld, AttentionWorld
+    rng = np.random.RandomState(13)
+    rec = {}
+
+    def scenes(B, N):
+        x = np.concatenate([rng.uniform(-4.5, 4.5, (B, N, 2)), rng.uniform(-1.2, 1.2, (B, N, 2))], axis=2)
+        x[::7, :, 2:] = 0.0                                    # standing crowds
+        return x.reshape(B, N * 4).astype(np.float32)
+    for N in (1, 5, 10):
+        torch.manual_seed(130 + N)
+        m = MlpWorld(N).eval()
+        x = scenes(192, N)
+        with torch.no_grad():
+            y = m(torch.from_numpy(x)).numpy()
+        rec.update(_state_dict_arrays(m, "mlp%d_w__" % N))
+        rec["mlp%d_in" % N], rec["mlp%d_out" % N] = x, y
+    torch.manual_seed(139)
+    a = AttentionWorld().eval()
+    rec.update(_state_dict_arrays(a, "attn_w__"))
+    for N in (2, 5, 10):
+        x = scenes(192, N)
+        with torch.no_grad():
+            y = a(torch.from_numpy(x)).numpy()
+        rec["attn%d_in" % N], rec["attn%d_out" % N] = x, y
+        rec["attn%d_weights0" % N] = np.asarray(a.attention_weights, np.float32)        # scene 0's attention weights
+    np.savez_compressed(os.path.join(OUT, "g13_world.npz"), **rec)
+    print("g13_world: %d arrays" % len(rec))
+
+
+FAMILIES = {"g13": g13_world, "g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}

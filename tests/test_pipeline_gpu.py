@@ -136,6 +136,34 @@ def test_attention_world_kernel_matches_torch_module(N):
             assert float((part[e, :n] - ref).abs().max()) <= 1e-5, e
 
 
+@pytest.mark.parametrize("case", ["mlp1", "mlp5", "mlp10", "attn2", "attn5", "attn10"])
+def test_world_kernels_match_reference_outputs(case, golden_dir):
+    """mcn_mlp_world_step / mcn_attn_world_step against g13_world.npz = the REAL reference's MlpWorld (eval) and
+    AttentionWorld forward (crowd_nav/policy/world_model.py:22-106) on 192 seeded scenes with seeded weights: float32
+    networks in another summation order, 1e-5 on the predicted velocities (the float tolerance of the path)."""
+    import torch
+    from modelcrowdnav_amd.envs import VecModelCrowdSim
+    from modelcrowdnav_amd.policy.world_model import AttentionWorld, MlpWorld, VecAttnWorld, VecMlpWorld, vec_world
+    from tests import helpers as H
+    g = np.load(os.path.join(golden_dir, "g13_world.npz"))
+    is_mlp = case.startswith("mlp")
+    N = int(case[3:] if is_mlp else case[4:])
+    pref = case + "_w__" if is_mlp else "attn_w__"
+    dev = torch.device("cuda", 0)
+    m = MlpWorld(N) if is_mlp else AttentionWorld()
+    m.load_state_dict({k[len(pref):].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith(pref)})
+    m.to(dev).eval()
+    x = g[case + "_in"].reshape(192, N, 4)
+    env = H.make_vec_env(192, N, cls=VecModelCrowdSim)
+    env.hpos.copy_(torch.from_numpy(x[:, :, :2].astype(np.float64)))
+    env.hvel.copy_(torch.from_numpy(x[:, :, 2:].astype(np.float64)))
+    world = vec_world(m, env)
+    assert isinstance(world, VecMlpWorld if is_mlp else VecAttnWorld)
+    got = world(env.hpos).cpu().numpy().reshape(192, 2 * N)
+    err = np.abs(got - g[case + "_out"]).max()
+    assert err <= 1e-5, err
+
+
 def test_e1_model_crowd_sim_steps_with_a_torch_world_module():
     """The reference's E = 1 surface (model_crowd_sim.py:398-417): `env.sim_world = MlpWorld(...)` -- a plain nn.Module,
     not an SGANWorld -- gets the scene as one float32 row and its output row moves the humans."""

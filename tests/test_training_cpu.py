@@ -244,6 +244,28 @@ def test_world_model_modules_match_reference_parameter_names():
     assert out.shape == (4, 10) and a.attention_weights.shape == (5,)
 
 
+@pytest.mark.parametrize("case", ["mlp1", "mlp5", "mlp10", "attn2", "attn5", "attn10"])
+def test_world_model_modules_match_reference_outputs(case, golden_dir):
+    """g13_world.npz = the reference's own MlpWorld (eval) / AttentionWorld forward (world_model.py:22-106) on seeded
+    scenes: this repo's modules, loaded with the same weights, give the same rows (same torch ops on the same CPU;
+    1e-6 leaves room for a differently blocked GEMM) and the same scene-0 attention weights."""
+    from modelcrowdnav_amd.policy.world_model import MlpWorld, AttentionWorld
+    g = np.load(os.path.join(golden_dir, "g13_world.npz"))
+    N = int(case[3:] if case.startswith("mlp") else case[4:])
+    pref = case + "_w__" if case.startswith("mlp") else "attn_w__"
+    m = MlpWorld(N) if case.startswith("mlp") else AttentionWorld()
+    m.load_state_dict({k[len(pref):].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith(pref)})
+    m.eval()
+    with torch.no_grad():
+        y = m(torch.from_numpy(g[case + "_in"])).numpy()
+    want = g[case + "_out"]
+    assert y.shape == want.shape == (192, 2 * N)
+    assert np.abs(y - want).max() <= 1e-6
+    assert np.abs(want).max() > (0.05 if case.startswith("mlp") else 0.01)
+    if case.startswith("attn"):
+        np.testing.assert_allclose(np.asarray(m.attention_weights), g[case + "_weights0"], rtol=0, atol=1e-6)
+
+
 def test_world_model_trainer_early_stopping_and_best_weights(tmp_path):
     """Trainer_Sim (trainer_sim.py:26-110): fits MlpWorld to a synthetic 'next velocity = damped current velocity'
     law, returns the best validation loss, restores the best weights and records model.mse."""

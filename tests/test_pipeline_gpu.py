@@ -155,6 +155,7 @@ def test_world_kernels_match_reference_outputs(case, golden_dir):
     m.to(dev).eval()
     x = g[case + "_in"].reshape(192, N, 4)
     env = H.make_vec_env(192, N, cls=VecModelCrowdSim)
+    H.upload(env, H.random_state(np.random.RandomState(0), 192, N))         # allocates the state; overwritten below
     env.hpos.copy_(torch.from_numpy(x[:, :, :2].astype(np.float64)))
     env.hvel.copy_(torch.from_numpy(x[:, :, 2:].astype(np.float64)))
     world = vec_world(m, env)

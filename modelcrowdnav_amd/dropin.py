@@ -98,3 +98,13 @@ def install():
         except Exception:            # already registered with a real gym
             pass
     return sorted(_MAP)
+
+
+def install_rvo2(force=False):
+    """The narrowest drop-in: keep the reference's own crowd_sim / crowd_nav packages and replace only the native module
+    they import (`import rvo2`, orca.py:2, crowd_sim.py:5) by modelcrowdnav_amd.rvo2, whose PyRVOSimulator.doStep() is one
+    mcn_orca_batch launch.  A real rvo2 that is already imported stays unless `force`."""
+    from . import rvo2
+    if force or "rvo2" not in sys.modules:
+        sys.modules["rvo2"] = rvo2
+    return sys.modules["rvo2"]

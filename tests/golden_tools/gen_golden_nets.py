@@ -19,6 +19,9 @@
               weights before / after, losses                                   (trainer.py:19-82)
   g13_world   MlpWorld (eval mode) and AttentionWorld forward on seeded scenes with seeded default-init weights
                                                                       (world_model.py:22-106)
+  g14_model_env ModelCrowdSim's own host logic: reset with its generators (initial velocities, no reseed), reset(-1),
+              set_current_state, and hand-driven episodes whose humans are moved by an MlpWorld module through
+              step(new_v=None) / onestep_lookahead                     (model_crowd_sim.py:94-232,268-345,398-441)
   g8_datagen  DataGen.gen_data_from_explore_in_mix on a synthetic recorded set: replay-then-freeze and
               replay-then-imagine (MlpWorld) samples, memory contents in IL and RL mode
                                                                       (datagen.py:379-543)
@@ -529,4 +532,99 @@ def g13_world():
     print("g13_world: %d arrays" % len(rec))
 
 
-FAMILIES = {"g13": g13_world, "g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}
+def g14_model_env():
+    """The reference's ModelCrowdSim driven as its callers do (train_model_based_sgan.py, datagen.py:434-476)."""
+    from crowd_sim.envs.utils.state import ObservableState, FullState
+    from crowd_sim.envs.utils.action import ActionXY
+    from crowd_nav.policy.world_model import MlpWorld
+    rec, meta, k = {}, [], 0
+    # ---- reset: the seeded branch does not reseed numpy (model_crowd_sim.py:296 is commented out): the caller's
+    # global generator state decides, consecutive resets continue the stream
+    for robot_policy in ("sarl", "orca"):
+        for rule in ("circle_crossing", "square_crossing", "mixed"):
+            # (10 humans with random radii can jam the reference's rejection loop for ever: 20 positions + goals of up
+            # to 1.2 m spacing on a 25 m circle)
+            for N, rnd in ((5, False), (10, False), (3, True), (5, True)):
+                env, robot, pol = G.make_env("ModelCrowdSim", robot_policy=robot_policy, human_num=N, randomize=rnd,
+                                             train_val_sim=rule, test_sim=rule)
+                for phase in ("test", "val", "train"):
+                    np.random.seed(1400 + k)
+                    for rep in range(3):
+                        env.human_num = N
+                        env.reset(phase, 7 if rep == 0 else None)
+                        rob, hum = G.full_state_rows(env)
+                        rec["reset_rob_%d" % k], rec["reset_hum_%d" % k] = rob, hum
+                        meta.append((robot_policy == "sarl", rule, N, rnd, phase, rep, 1400 + k - rep, hum.shape[0],
+                                     env.case_counter[phase]))
+                        k += 1
+    for j, name in enumerate(("multiagent", "rule", "N", "randomize", "phase", "rep", "seed", "nh", "counter_after")):
+        rec["reset_meta_" + name] = np.array([m[j] for m in meta])
+    rec["case_size_train"] = np.array(env.case_size["train"], np.int64)
+    env, robot, pol = G.make_env("ModelCrowdSim", robot_policy="orca", human_num=5)
+    env.reset("test", -1)                                           # the three-human debugging scene
+    rec["debug_rob"], rec["debug_hum"] = G.full_state_rows(env)
+    # ---- set_current_state
+    rng = np.random.RandomState(14)
+    env, robot, pol = G.make_env("ModelCrowdSim", robot_policy="orca", human_num=5)
+    for c in range(4):
+        n = (4, 5, 2, 7)[c]
+        rows = np.concatenate([rng.uniform(-4, 4, (n, 2)), rng.uniform(-1, 1, (n, 2)), rng.uniform(0.2, 0.5, (n, 1))], 1)
+        obs = [ObservableState(*r) for r in rows]
+        info = None if c == 0 else FullState(*rng.uniform(-4, 4, 2), 0.3, -0.2, 0.3, *rng.uniform(-4, 4, 2), 1.0, 0.7)
+        env.set_current_state(obs, info, phase=("train", "val", "test", "train")[c])
+        rec["scs_obs_%d" % c] = rows
+        rec["scs_info_%d" % c] = np.zeros(0) if info is None else np.array([info.px, info.py, info.gx, info.gy])
+        rec["scs_rob_%d" % c], rec["scs_hum_%d" % c] = G.full_state_rows(env)
+        rec["scs_global_time_%d" % c] = np.array(env.global_time, np.float64)
+    # ---- episodes: humans moved by an MlpWorld module (the non-SGAN branch of :398-407), robot actions from the table
+    table = _sarl_policy(0).__class__          # noqa: F841  (imports the policy package once)
+    pol0 = _sarl_policy(0)
+    pol0.kinematics = "holonomic"
+    pol0.build_action_space(1.0)
+    acts = np.array([[a.vx, a.vy] for a in pol0.action_space], np.float64)
+    for e, (N, rule, seed) in enumerate(((5, "circle_crossing", 3), (5, "square_crossing", 4), (3, "circle_crossing", 5),
+                                         (10, "circle_crossing", 6), (2, "square_crossing", 9),
+                                         (2, "circle_crossing", 11))):
+        env, robot, pol = G.make_env("ModelCrowdSim", robot_policy="orca", human_num=N, train_val_sim=rule, test_sim=rule)
+        env.device = torch.device("cpu")
+        torch.manual_seed(140 + e)
+        world = MlpWorld(N).eval()
+        with torch.no_grad():
+            for prm in world.parameters():
+                prm.mul_(1.5)
+        env.sim_world = world
+        rec.update(_state_dict_arrays(world, "epi%d_world__" % e))
+        np.random.seed(seed)
+        env.reset("test")                       # 'train' would make one human: the ORCA robot is not multiagent_training
+        rob0, hum0 = G.full_state_rows(env)
+        arng = np.random.RandomState(40 + e)
+        steps = {key: [] for key in ("act", "look_obs", "look_reward", "look_done", "look_info", "obs", "reward", "done",
+                                     "info", "rob", "hum", "time")}
+        done = False
+        while not done and len(steps["act"]) < 110:
+            a = acts[0] if len(steps["act"]) % 7 == 6 else acts[1 + 5 * 4 + int(arng.randint(0, 5))]   # mostly towards +y
+            if e % 2:
+                a = acts[1 + 5 * 4 + 4]                                # straight to the goal at full speed
+            elif arng.rand() < 0.3:
+                a = acts[int(arng.randint(0, 81))]
+            with torch.no_grad():
+                ob, r, d, info = env.onestep_lookahead(ActionXY(*a))
+            steps["look_obs"].append([[o.px, o.py, o.vx, o.vy, o.radius] for o in ob])
+            steps["look_reward"].append(r); steps["look_done"].append(d); steps["look_info"].append(G.info_code(info))
+            with torch.no_grad():
+                ob, r, done, info = env.step(ActionXY(*a))
+            steps["act"].append(a)
+            steps["obs"].append([[o.px, o.py, o.vx, o.vy, o.radius] for o in ob])
+            steps["reward"].append(r); steps["done"].append(done); steps["info"].append(G.info_code(info))
+            rob, hum = G.full_state_rows(env)
+            steps["rob"].append(rob); steps["hum"].append(hum); steps["time"].append(env.global_time)
+        rec["epi%d_seed" % e] = np.array(seed); rec["epi%d_rule" % e] = np.array(rule)
+        rec["epi%d_rob0" % e], rec["epi%d_hum0" % e] = rob0, hum0
+        for key, val in steps.items():
+            rec["epi%d_%s" % (e, key)] = np.array(val, np.float64 if key not in ("done", "look_done", "info", "look_info") else np.int32)
+        print("  episode %d: %d steps, ends with info %d" % (e, len(steps["act"]), steps["info"][-1]))
+    np.savez_compressed(os.path.join(OUT, "g14_model_env.npz"), **rec)
+    print("g14_model_env: %d arrays, %d resets" % (len(rec), k))
+
+
+FAMILIES = {"g14": g14_model_env, "g13": g13_world, "g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}

@@ -113,7 +113,7 @@ class VecExplorer(object):
     def run_k_episodes(self, k, phase, update_memory=False, imitation_learning=False, episode=None,
                        print_failure=False, returnRate=True, returnNav=False, action_fn=None, max_steps=None,
                        total_envs=None, action_seq=None, device_scenarios=None, stay=False, update_raw_ob=False,
-                       cacheFile=None):
+                       cacheFile=None, test_case=None):
         """Returns what Explorer.run_k_episodes returns (explorer.py:146-151):
         (avg cumulative reward, success rate, collision rate, timeout rate[, avg nav time])
         or counts instead of rates when returnRate is False.  `action_fn(env, t) -> [E,2]` overrides the
@@ -126,7 +126,8 @@ class VecExplorer(object):
         Data collection (explorer.py:60-85,112-121), single process only: `stay` keeps the robot still; with
         `self.raw_memory` set every step pushes `(ob, reward, done, info)` (ob = [N,5] array of the humans after the
         step, info = code) in episode order; `update_raw_ob` pushes world-model pairs into `self.rawob`; `cacheFile`
-        (a directory) gets one SGAN text file per episode."""
+        (a directory) gets one SGAN text file per episode.
+        `test_case` plays that one case k times (explorer.py:54 hands it to every reset; the counter ends one past it)."""
         env = self.env
         rank, ws = mdist.world()
         E_local = env.num_envs
@@ -141,6 +142,10 @@ class VecExplorer(object):
         size = env.case_size[phase]
         rounds = -(-k // E_total)                               # episodes per env (ceil)
         cases = [(first + i) % size for i in range(rounds * E_total)]
+        if test_case is not None:
+            if device_scenarios is not None:
+                raise NotImplementedError("test_case with device scenarios")
+            cases = [test_case] * (rounds * E_total)
         uniq = sorted(set(cases))
         if device_scenarios is None:
             pool = S.scenario_pool(env.spec(), phase, uniq, n, rule)
@@ -240,7 +245,7 @@ class VecExplorer(object):
             self._emit_collected(torch.stack(col_cur).cpu().numpy(), torch.stack(col_ob).cpu().numpy(),
                                  torch.stack(col_r).cpu().numpy(), torch.stack(col_d).cpu().numpy(),
                                  torch.stack(col_i).cpu().numpy(), k, rounds, E_total, update_raw_ob, cacheFile)
-        env.case_counter[phase] = (first + k) % size
+        env.case_counter[phase] = (first + k) % size if test_case is None else (test_case + 1) % size
         # records in global episode order: episode g = r * E_total + global_env
         # (the envs' "too close" counters ride in the same collective, in the rows of their first episode)
         dng = torch.zeros(2, E_local, rounds, dtype=torch.float64, device=bufs["fin_return"].device)

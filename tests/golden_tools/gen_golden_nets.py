@@ -22,6 +22,8 @@
   g14_model_env ModelCrowdSim's own host logic: reset with its generators (initial velocities, no reseed), reset(-1),
               set_current_state, and hand-driven episodes whose humans are moved by an MlpWorld module through
               step(new_v=None) / onestep_lookahead                     (model_crowd_sim.py:94-232,268-345,398-441)
+  g15_explorer Explorer.run_k_episodes itself (explorer.py:36-151): imitation-learning collection with the ORCA robot,
+              a greedy SARL robot, the stay / raw_memory / rawob / cacheFile data-collection mode, counts and rates
   g8_datagen  DataGen.gen_data_from_explore_in_mix on a synthetic recorded set: replay-then-freeze and
               replay-then-imagine (MlpWorld) samples, memory contents in IL and RL mode
                                                                       (datagen.py:379-543)
@@ -627,4 +629,78 @@ def g14_model_env():
     print("g14_model_env: %d arrays, %d resets" % (len(rec), k))
 
 
-FAMILIES = {"g14": g14_model_env, "g13": g13_world, "g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}
+def g15_explorer():
+    """The reference's own Explorer.run_k_episodes (crowd_nav/utils/explorer.py:36-151) on the reference CrowdSim (ORCA
+    humans through the rvo2 stand-in).  explorer.py:51 reads `np.NaN`, an alias numpy 2.x removed: this tool process
+    (only) puts it back before the call -- the reference file is untouched."""
+    import tempfile
+    from crowd_nav.utils.explorer import Explorer
+    from crowd_nav.utils.memory import ReplayMemory
+    if not hasattr(np, "NaN"):
+        np.NaN = np.nan
+    rec = {}
+    dev = torch.device("cpu")
+    target = _sarl_policy(51)
+    target.kinematics = "holonomic"
+    rec.update(_state_dict_arrays(target.model, "target_w__"))
+
+    def memory_arrays(mem, tag):
+        if len(mem.memory):
+            rec[tag + "_mem_states"] = np.stack([m[0].numpy() for m in mem.memory])
+            rec[tag + "_mem_values"] = np.array([float(m[1]) for m in mem.memory], np.float32)
+        else:
+            rec[tag + "_mem_states"] = np.zeros((0, 5, 13), np.float32)
+            rec[tag + "_mem_values"] = np.zeros(0, np.float32)
+
+    # ---- (1) imitation learning: the ORCA demonstrator of train.py:150-160 (safety_space from train.config)
+    for tag, phase, k, kw in (("il_val", "val", 12, dict(returnNav=True)),
+                              ("il_train", "train", 9, dict(returnRate=False)),
+                              ("il_fixed_case", "test", 3, dict(test_case=3, returnNav=True))):
+        env, robot, pol = G.make_env("CrowdSim", robot_policy="orca", human_num=5)
+        pol.multiagent_training = True
+        pol.safety_space = 0.15
+        mem = ReplayMemory(100000)
+        ex = Explorer(env, robot, dev, mem, 0.9, target_policy=target)
+        out = ex.run_k_episodes(k, phase, update_memory=True, imitation_learning=True, **kw)
+        rec[tag + "_out"] = np.array(out, np.float64)
+        rec[tag + "_counter"] = np.array(env.case_counter[phase])
+        memory_arrays(mem, tag)
+        print("  %s: out %s, %d memory rows" % (tag, [round(float(x), 4) for x in out], len(mem.memory)))
+    # ---- (2) greedy SARL robot (seeded weights), RL value targets from a target network.  Phase 'train' with epsilon 0:
+    # the policy only keeps `last_state` in the train phase (multi_human_rl.py:60-61), which update_memory needs
+    torch.manual_seed(52)
+    env, robot, pol = G.make_env("CrowdSim", robot_policy="sarl", human_num=5)
+    rec.update(_state_dict_arrays(pol.model, "sarl_w__"))
+    mem = ReplayMemory(100000)
+    ex = Explorer(env, robot, dev, mem, 0.9, target_policy=pol)
+    ex.update_target_model(target.model)
+    pol.set_epsilon(0.0)
+    with torch.no_grad():
+        out = ex.run_k_episodes(6, "train", update_memory=True, imitation_learning=False, returnNav=True)
+    rec["sarl_train_out"] = np.array(out, np.float64)
+    memory_arrays(mem, "sarl_train")
+    print("  sarl_train: out %s, %d memory rows" % ([round(float(x), 4) for x in out], len(mem.memory)))
+    # ---- (3) data collection: robot stays, every step into raw_memory, world-model pairs, one SGAN text file per episode
+    for tag, stay in (("collect_stay", True), ("collect_orca", False)):
+        env, robot, pol = G.make_env("CrowdSim", robot_policy="orca", human_num=5)
+        pol.multiagent_training = True
+        ex = Explorer(env, robot, dev, None, 0.9)
+        ex.raw_memory, ex.rawob = ReplayMemory(100000), ReplayMemory(100000)
+        with tempfile.TemporaryDirectory() as d:
+            out = ex.run_k_episodes(4, "val", stay=stay, update_raw_ob=True, cacheFile=d, returnNav=True)
+            for i in range(4):
+                rec["%s_cache%d" % (tag, i + 1)] = np.array(open(os.path.join(d, "%d.txt" % (i + 1))).read())
+        rec[tag + "_out"] = np.array(out, np.float64)
+        raw = ex.raw_memory.memory
+        rec[tag + "_raw_ob"] = np.array([[[h.px, h.py, h.vx, h.vy, h.radius] for h in r[0]] for r in raw], np.float64)
+        rec[tag + "_raw_reward"] = np.array([r[1] for r in raw], np.float64)
+        rec[tag + "_raw_done"] = np.array([r[2] for r in raw], np.uint8)
+        rec[tag + "_raw_info"] = np.array([G.info_code(r[3]) for r in raw], np.int32)
+        rec[tag + "_pairs_cur"] = np.stack([p[0].numpy() for p in ex.rawob.memory])
+        rec[tag + "_pairs_next"] = np.stack([p[1].numpy() for p in ex.rawob.memory])
+        print("  %s: out %s, %d raw rows, %d pairs" % (tag, [round(float(x), 4) for x in out], len(raw), len(ex.rawob.memory)))
+    np.savez_compressed(os.path.join(OUT, "g15_explorer.npz"), **rec)
+    print("g15_explorer: %d arrays" % len(rec))
+
+
+FAMILIES = {"g15": g15_explorer, "g14": g14_model_env, "g13": g13_world, "g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}

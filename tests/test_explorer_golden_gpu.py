@@ -1,0 +1,139 @@
+"""The batched VecExplorer against g15_explorer.npz = the REAL reference's Explorer.run_k_episodes
+(crowd_nav/utils/explorer.py:36-151) on the reference CrowdSim: returned statistics, replay-memory contents (imitation
+learning with the ORCA demonstrator, RL value targets with a SARL robot and a target network) and the data-collection
+side channels (raw_memory rows, world-model pairs, SGAN cache files).  The reference's ORCA humans were solved by the
+rvo2 stand-in (= the C oracle): plumbing pinned, solver unpinned."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests import helpers as H  # noqa: E402
+
+
+def _load(model, g, pref):
+    import torch
+    model.load_state_dict({k[len(pref):].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith(pref)})
+
+
+def _sarl(g, pref, dev, phase):
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.policy.sarl import SARL
+    p = SARL()
+    p.configure(configs.policy_config())
+    p.kinematics = "holonomic"
+    _load(p.model, g, pref)
+    p.set_device(dev); p.set_phase(phase); p.time_step = 0.25
+    p.multiagent_training = True
+    return p
+
+
+def _check_memory(mem, g, tag, ordered):
+    """Memory rows against the reference's: same order when the batched explorer plays one env (its (env, time) order is
+    then the reference's (episode, time) order); otherwise matched one to one by nearest state."""
+    want_s, want_v = g[tag + "_mem_states"], g[tag + "_mem_values"]
+    assert len(mem) == want_s.shape[0] > 0
+    got_s = mem._states[:len(mem)].cpu().numpy()
+    got_v = mem._values[:len(mem), 0].cpu().numpy()
+    if not ordered:
+        a, b = got_s.reshape(len(mem), -1), want_s.reshape(len(mem), -1)
+        used, match = np.zeros(len(mem), bool), []
+        for row in b:                                               # nearest row not taken yet (a fixed test_case
+            d = np.abs(a - row).max(1)                              # repeats whole episodes)
+            d[used] = np.inf
+            match.append(int(d.argmin()))
+            used[match[-1]] = True
+        match = np.array(match)
+        got_s, got_v = got_s[match], got_v[match]
+    # states: float32 rotate() on another device: atan2 / cos / sin differ in the last place, which moves a rotated
+    # coordinate of magnitude m by a few 1e-7 * m (seen: 2.1e-6 at 2.1); values: float32 sums
+    np.testing.assert_allclose(got_s, want_s, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(got_v, want_v, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("E", [1, 4])
+@pytest.mark.parametrize("tag,phase,k,kw", [("il_val", "val", 12, dict(returnNav=True)),
+                                            ("il_train", "train", 9, dict(returnRate=False)),
+                                            ("il_fixed_case", "test", 3, dict(test_case=3, returnNav=True))])
+def test_imitation_learning_collection_matches_reference(tag, phase, k, kw, E, golden_dir):
+    """train.py:150-160: the ORCA demonstrator (safety_space 0.15) drives, states are transformed by the target policy,
+    values are discounted tail sums; only ReachGoal / Collision episodes feed the memory."""
+    import torch
+    from modelcrowdnav_amd.envs.policy.policy_factory import policy_factory
+    from modelcrowdnav_amd.rollout import VecExplorer
+    from modelcrowdnav_amd.utils.memory import ReplayMemory
+    g = np.load(os.path.join(golden_dir, "g15_explorer.npz"))
+    dev = torch.device("cuda", 0)
+    env = H.make_vec_env(E, 5)
+    env.track_human_times = False; env.export_human_actions = False
+    orca = policy_factory["orca"]()
+    orca.multiagent_training = True
+    orca.safety_space = 0.15
+    env.robot.set_policy(orca)
+    mem = ReplayMemory(100000, device=dev)
+    ex = VecExplorer(env, env.robot, gamma=0.9, policy=orca, memory=mem, target_policy=_sarl(g, "target_w__", dev, "test"))
+    out = ex.run_k_episodes(k, phase, update_memory=True, imitation_learning=True, **kw)
+    want = g[tag + "_out"]
+    assert len(out) == len(want) and tuple(out[1:]) == tuple(want[1:]), (out, want)
+    assert abs(out[0] - want[0]) < 1e-12
+    assert env.case_counter[phase] == int(g[tag + "_counter"])
+    _check_memory(mem, g, tag, ordered=(E == 1))
+
+
+@pytest.mark.parametrize("E", [1, 3])
+def test_sarl_robot_with_rl_value_targets_matches_reference(E, golden_dir):
+    """Greedy SARL robot in the train phase (epsilon 0), value targets r + gamma_bar * target_model(next state): the
+    chosen actions decide the trajectories, so the returned statistics hold only if every look-ahead picks the
+    reference's action (float32 value network on another device, strict-> argmax)."""
+    import torch
+    from modelcrowdnav_amd.rollout import VecExplorer
+    from modelcrowdnav_amd.utils.memory import ReplayMemory
+    g = np.load(os.path.join(golden_dir, "g15_explorer.npz"))
+    dev = torch.device("cuda", 0)
+    env = H.make_vec_env(E, 5)
+    env.track_human_times = False; env.export_human_actions = False
+    sarl = _sarl(g, "sarl_w__", dev, "train")
+    sarl.set_epsilon(0.0)
+    env.robot.set_policy(sarl)
+    sarl.set_env(env)
+    mem = ReplayMemory(100000, device=dev)
+    ex = VecExplorer(env, env.robot, gamma=0.9, policy=sarl, memory=mem)
+    ex.update_target_model(_sarl(g, "target_w__", dev, "test").model)
+    out = ex.run_k_episodes(6, "train", update_memory=True, imitation_learning=False, returnNav=True)
+    want = g["sarl_train_out"]
+    assert tuple(out[1:]) == tuple(want[1:]), (out, want)
+    assert abs(out[0] - want[0]) < 1e-9
+    _check_memory(mem, g, "sarl_train", ordered=(E == 1))
+
+
+@pytest.mark.parametrize("E", [1, 4, 3])
+@pytest.mark.parametrize("tag,stay", [("collect_stay", True), ("collect_orca", False)])
+def test_data_collection_matches_reference(tag, stay, E, golden_dir, tmp_path):
+    """explorer.py:60-85,112-121: raw_memory rows in episode order, world-model pairs of the steps where somebody
+    moves, one SGAN text file per episode -- byte for byte what the reference wrote."""
+    import torch
+    from modelcrowdnav_amd.envs.policy.policy_factory import policy_factory
+    from modelcrowdnav_amd.rollout import VecExplorer
+    g = np.load(os.path.join(golden_dir, "g15_explorer.npz"))
+    env = H.make_vec_env(E, 5)
+    env.track_human_times = False; env.export_human_actions = False
+    orca = policy_factory["orca"]()
+    orca.multiagent_training = True
+    env.robot.set_policy(orca)
+    ex = VecExplorer(env, env.robot, gamma=0.9, policy=orca)
+    ex.raw_memory, ex.rawob = [], []
+    out = ex.run_k_episodes(4, "val", stay=stay, update_raw_ob=True, cacheFile=str(tmp_path), returnNav=True)
+    want = g[tag + "_out"]
+    assert tuple(out[1:]) == tuple(want[1:]) and abs(out[0] - want[0]) < 1e-12, (out, want)
+    assert len(ex.raw_memory) == g[tag + "_raw_ob"].shape[0]
+    assert np.array_equal(np.stack([r[0] for r in ex.raw_memory]), g[tag + "_raw_ob"])
+    assert np.array_equal(np.array([r[1] for r in ex.raw_memory]), g[tag + "_raw_reward"])
+    assert np.array_equal(np.array([r[2] for r in ex.raw_memory], np.uint8), g[tag + "_raw_done"])
+    assert np.array_equal(np.array([r[3] for r in ex.raw_memory], np.int32), g[tag + "_raw_info"])
+    assert len(ex.rawob) == g[tag + "_pairs_cur"].shape[0]
+    assert np.array_equal(torch.stack([p[0] for p in ex.rawob]).numpy(), g[tag + "_pairs_cur"])
+    assert np.array_equal(torch.stack([p[1] for p in ex.rawob]).numpy(), g[tag + "_pairs_next"])
+    for i in range(1, 5):
+        assert open(tmp_path / ("%d.txt" % i)).read() == str(g["%s_cache%d" % (tag, i)]), i

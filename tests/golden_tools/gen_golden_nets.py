@@ -24,6 +24,8 @@
               step(new_v=None) / onestep_lookahead                     (model_crowd_sim.py:94-232,268-345,398-441)
   g15_explorer Explorer.run_k_episodes itself (explorer.py:36-151): imitation-learning collection with the ORCA robot,
               a greedy SARL robot, the stay / raw_memory / rawob / cacheFile data-collection mode, counts and rates
+  g16_orca_robot BASELINE config 1 as the reference runs it (test.py --policy orca): CrowdSim with an ORCA robot, per-step
+              actions / rewards / states, then get_human_times() to the end          (test.py:64-109, crowd_sim.py:219-258)
   g8_datagen  DataGen.gen_data_from_explore_in_mix on a synthetic recorded set: replay-then-freeze and
               replay-then-imagine (MlpWorld) samples, memory contents in IL and RL mode
                                                                       (datagen.py:379-543)
@@ -703,4 +705,38 @@ def g15_explorer():
     print("g15_explorer: %d arrays" % len(rec))
 
 
-FAMILIES = {"g15": g15_explorer, "g14": g14_model_env, "g13": g13_world, "g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}
+def g16_orca_robot():
+    """test.py:64-109 with --policy orca: the reference CrowdSim (visible and invisible robot), ORCA robot and humans through
+    the rvo2 stand-in; after the robot has arrived, crowd_sim.py:219-258 runs everybody to the end."""
+    rec = {}
+    for vis in (False, True):
+        env, robot, pol = G.make_env("CrowdSim", robot_policy="orca", human_num=5, robot_visible=vis)
+        for case in (0, 3, 6, 11):
+            ob = env.reset("test", case)
+            done = False
+            A, R, I, ST = [], [], [], []
+            while not done:
+                action = robot.act(ob)
+                ob, reward, done, info = env.step(action)
+                rob, hum = G.full_state_rows(env)
+                A.append([action.vx, action.vy]); R.append(reward); I.append(G.info_code(info))
+                ST.append(np.concatenate([rob, hum.ravel()]))
+            key = "v%d_c%d_" % (vis, case)
+            rec[key + "actions"], rec[key + "rewards"] = np.array(A), np.array(R)
+            rec[key + "info"], rec[key + "states"] = np.array(I), np.array(ST)
+            rec[key + "time"] = np.array(env.global_time)
+            rec[key + "human_times_step"] = np.array(env.human_times, np.float64)
+            if I[-1] == G.INFO_CODE["ReachGoal"]:
+                ht = env.get_human_times()          # test.py:106: after the robot's last step has put it on the goal
+                rob, hum = G.full_state_rows(env)
+                rec[key + "human_times"] = np.array(ht, np.float64)
+                rec[key + "end_rob"], rec[key + "end_hum"] = rob, hum
+                rec[key + "end_time"] = np.array(env.global_time)
+                rec[key + "n_states"] = np.array(len(env.states))
+            print("  visible %d case %d: %d steps, outcome %d%s" % (vis, case, len(A), I[-1],
+                  ", human times %s" % [round(float(x), 2) for x in rec[key + "human_times"]] if key + "human_times" in rec else ""))
+    np.savez_compressed(os.path.join(OUT, "g16_orca_robot.npz"), **rec)
+    print("g16_orca_robot: %d arrays" % len(rec))
+
+
+FAMILIES = {"g16": g16_orca_robot, "g15": g15_explorer, "g14": g14_model_env, "g13": g13_world, "g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}

@@ -195,6 +195,59 @@ def test_get_human_times_matches_oracle_simulation():
     assert [h.get_position() for h in env.humans] == [tuple(p) for p in pos64[1:].tolist()]
 
 
+@pytest.mark.parametrize("visible", [False, True])
+def test_crowdsim_e1_orca_robot_and_human_times_match_reference(visible, golden_dir):
+    """g16_orca_robot.npz = BASELINE config 1 as the REAL reference runs it (test.py:64-109 with --policy orca; ORCA
+    through the rvo2 stand-in): this build's CrowdSim + ORCA robot takes the same float32 actions, collects the same
+    rewards / outcomes and agent states step by step, and get_human_times() (crowd_sim.py:219-258, one mcn_orca_batch
+    launch per simulated step) returns the same first-arrival times, end positions, clock and number of states."""
+    import torch
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.envs import CrowdSim
+    from modelcrowdnav_amd.envs.utils.robot import Robot
+    from modelcrowdnav_amd.envs.policy.policy_factory import policy_factory
+    g = np.load(os.path.join(golden_dir, "g16_orca_robot.npz"))
+    cfg = configs.env_config(**{"robot.visible": "true" if visible else "false"})
+    env = CrowdSim()
+    env.configure(cfg)
+    robot = Robot(cfg, "robot")
+    pol = policy_factory["orca"]()
+    pol.configure(cfg)
+    robot.set_policy(pol)
+    env.set_robot(robot)
+    pol.set_phase("test"); pol.set_device(torch.device("cuda", 0)); pol.set_env(env)
+
+    def rows():
+        r = env.robot
+        rob = [r.px, r.py, r.vx, r.vy, r.radius, r.gx, r.gy, r.v_pref, r.theta]
+        hum = [[h.px, h.py, h.vx, h.vy, h.radius, h.gx, h.gy, h.v_pref, h.theta] for h in env.humans]
+        return np.array(rob), np.array(hum)
+    arrived = 0
+    for case in (0, 3, 6, 11):
+        key = "v%d_c%d_" % (visible, case)
+        ob = env.reset("test", case)
+        A, I = g[key + "actions"], g[key + "info"]
+        for t in range(A.shape[0]):
+            action = robot.act(ob)
+            assert (action.vx, action.vy) == (A[t, 0], A[t, 1]), (case, t)
+            ob, reward, done, info = env.step(action)
+            assert reward == g[key + "rewards"][t] and info.code == I[t] and done == (t == A.shape[0] - 1), (case, t)
+            rob, hum = rows()
+            assert np.array_equal(np.concatenate([rob, hum.ravel()]), g[key + "states"][t]), (case, t)
+        assert env.global_time == float(g[key + "time"])
+        assert np.array_equal(np.array(env.human_times, np.float64), g[key + "human_times_step"])
+        if key + "human_times" in g.files:
+            arrived += 1
+            assert np.array_equal(np.array(env.get_human_times(), np.float64), g[key + "human_times"]), case
+            rob, hum = rows()
+            assert np.array_equal(rob, g[key + "end_rob"]) and np.array_equal(hum, g[key + "end_hum"]), case
+            assert env.global_time == float(g[key + "end_time"]) and len(env.states) == int(g[key + "n_states"])
+        else:
+            with pytest.raises(ValueError):
+                env.get_human_times()               # 'Episode is not done yet' (the robot collided on the way)
+    assert arrived >= 2
+
+
 def test_crowdsim_e1_sarl_episode_matches_reference(golden_dir):
     """G7: reference CrowdSim + SARL (seeded weights) episodes; this build's CrowdSim + SARL must take the same
     actions and collect the same rewards step by step."""

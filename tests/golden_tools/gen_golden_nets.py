@@ -26,6 +26,8 @@
               a greedy SARL robot, the stay / raw_memory / rawob / cacheFile data-collection mode, counts and rates
   g16_orca_robot BASELINE config 1 as the reference runs it (test.py --policy orca): CrowdSim with an ORCA robot, per-step
               actions / rewards / states, then get_human_times() to the end          (test.py:64-109, crowd_sim.py:219-258)
+  g17_sarl_unicycle MultiHumanRL.predict with a unicycle robot ((v, r) actions, heading-dependent propagate, the theta
+              feature): action_values + chosen action                  (cadrl.py:82-129,217-252, multi_human_rl.py:11-63)
   g8_datagen  DataGen.gen_data_from_explore_in_mix on a synthetic recorded set: replay-then-freeze and
               replay-then-imagine (MlpWorld) samples, memory contents in IL and RL mode
                                                                       (datagen.py:379-543)
@@ -739,4 +741,44 @@ def g16_orca_robot():
     print("g16_orca_robot: %d arrays" % len(rec))
 
 
-FAMILIES = {"g16": g16_orca_robot, "g15": g15_explorer, "g14": g14_model_env, "g13": g13_world, "g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}
+def g17_sarl_unicycle():
+    from crowd_sim.envs.utils.state import FullState, ObservableState, JointState
+    rng = np.random.RandomState(17)
+    rec = {}
+    p = _sarl_policy(17)
+    p.kinematics = "unicycle"
+    rec.update(_state_dict_arrays(p.model, "w__"))
+    for N in (5, 10, 2):
+        states, vals, acts = [], [], []
+        for s_ in range(40):
+            rpx, rpy = rng.uniform(-3, 3, 2)
+            near_goal = s_ % 8 == 7
+            gx, gy = (rpx + rng.uniform(-0.2, 0.2), rpy + rng.uniform(-0.2, 0.2)) if near_goal else rng.uniform(-4, 4, 2)
+            theta = rng.uniform(-np.pi, 2 * np.pi)
+            sp = rng.uniform(0, 1)
+            me = FullState(rpx, rpy, sp * np.cos(theta), sp * np.sin(theta), 0.3, gx, gy, 1.0, theta)
+            hs = []
+            for i in range(N):
+                if s_ % 3 == 0 and i < 2:
+                    a, d = rng.uniform(0, 2 * np.pi), rng.uniform(0.5, 1.3)
+                    hx, hy = rpx + d * np.cos(a), rpy + d * np.sin(a)
+                else:
+                    hx, hy = rng.uniform(-4, 4, 2)
+                hs.append(ObservableState(hx, hy, rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(0.3, 0.5)))
+            js = JointState(me, hs)
+            with torch.no_grad():
+                act = p.predict(js)
+            states.append((np.array([me.px, me.py, me.vx, me.vy, me.radius, me.gx, me.gy, me.v_pref, me.theta]),
+                           np.array([[h.px, h.py, h.vx, h.vy, h.radius] for h in hs])))
+            acts.append([act.v, act.r])
+            vals.append(np.array(p.action_values) if not p.reach_destination(js) else np.full(81, np.nan))
+        rec["N%d_self" % N] = np.array([s_[0] for s_ in states])
+        rec["N%d_humans" % N] = np.array([s_[1] for s_ in states])
+        rec["N%d_values" % N] = np.array(vals)
+        rec["N%d_action" % N] = np.array(acts)
+    rec["table"] = np.array([[a.v, a.r] for a in p.action_space])
+    np.savez_compressed(os.path.join(OUT, "g17_sarl_unicycle.npz"), **rec)
+    print("g17_sarl_unicycle: %d arrays" % len(rec))
+
+
+FAMILIES = {"g17": g17_sarl_unicycle, "g16": g16_orca_robot, "g15": g15_explorer, "g14": g14_model_env, "g13": g13_world, "g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}

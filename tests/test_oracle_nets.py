@@ -46,6 +46,29 @@ def test_predict_values_and_argmax(golden_dir):
                 assert tuple(table[idx]) == tuple(g[key + "action"][s])
 
 
+def test_predict_unicycle_values_and_argmax(golden_dir):
+    """g17_sarl_unicycle.npz = the reference's MultiHumanRL.predict with kinematics 'unicycle': (v, r) table
+    (cadrl.py:97-99), heading-dependent propagate (:118-124), theta kept as a feature (:236-237)."""
+    g = np.load(os.path.join(golden_dir, "g17_sarl_unicycle.npz"))
+    w = _weights(g, "w__")
+    table = g["table"]
+    assert table.shape == (81, 2) and table[1, 1] == -np.pi / 4
+    seen = 0
+    for N in (5, 10, 2):
+        for s in range(g["N%d_self" % N].shape[0]):
+            want = g["N%d_values" % N][s]
+            if np.isnan(want[0]):
+                assert tuple(g["N%d_action" % N][s]) == (0, 0)        # reach_destination short-circuit: ActionRot(0, 0)
+                continue
+            vals, idx = pyref.sarl_predict(w, g["N%d_self" % N][s], g["N%d_humans" % N][s], table, kinematics="unicycle")
+            np.testing.assert_allclose(vals, want, rtol=0, atol=5e-6)
+            top2 = np.sort(want)[-2:]
+            if top2[1] - top2[0] > 1e-5:
+                assert tuple(table[idx]) == tuple(g["N%d_action" % N][s]), (N, s)
+            seen += 1
+    assert seen > 90
+
+
 def test_sgan_generator(golden_dir):
     g = np.load(os.path.join(golden_dir, "g6_sgan.npz"))
     for tag in ("np", "p"):

@@ -225,6 +225,41 @@ def test_unicycle_lookahead_matches_oracle():
         np.testing.assert_allclose(values[e], ref, rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("N", [5, 10, 2])
+def test_unicycle_predict_matches_reference_fixture(N, golden_dir):
+    """g17_sarl_unicycle.npz = the REAL reference's predict with a unicycle robot: the 40 recorded states go through
+    one predict_batch (mcn_sarl_predict, kinematics 1) -- 81 action values to the path's tolerance, the reference's
+    (v, r) action wherever its top two values are further apart than that, (0, 0) where the robot stands on its goal."""
+    import torch
+    g = np.load(os.path.join(golden_dir, "g17_sarl_unicycle.npz"))
+    pol = _policy(_weights(g, "w__"))
+    pol.kinematics = "unicycle"
+    pol.action_space = None
+    me, hum = g["N%d_self" % N], g["N%d_humans" % N]
+    E = me.shape[0]
+    env = H.make_vec_env(E, N, kinematics="unicycle")
+    st = H.random_state(np.random.RandomState(0), E, N)
+    st.rpx[:], st.rpy[:], st.rvx[:], st.rvy[:], st.rr[:] = me[:, 0], me[:, 1], me[:, 2], me[:, 3], me[:, 4]
+    st.rgx[:], st.rgy[:], st.rtheta[:] = me[:, 5], me[:, 6], me[:, 8]
+    st.hpx[:], st.hpy[:], st.hvx[:], st.hvy[:], st.hr[:] = (hum[:, :, c] for c in range(5))
+    H.upload(env, st)
+    actions, best, values = pol.predict_batch(env, want_values=True)
+    values, actions = values.cpu().numpy(), actions.cpu().numpy()
+    assert np.array_equal(pol._action_table, g["table"])
+    checked = 0
+    for e in range(E):
+        want = g["N%d_values" % N][e]
+        if np.isnan(want[0]):
+            assert tuple(actions[e]) == (0.0, 0.0)
+            continue
+        np.testing.assert_allclose(values[e], want, rtol=0, atol=TOL)
+        top2 = np.sort(want)[-2:]
+        if top2[1] - top2[0] > 2 * TOL:
+            assert tuple(actions[e]) == tuple(g["N%d_action" % N][e]), e
+            checked += 1
+    assert checked > 25
+
+
 def test_per_env_pedestrian_counts():
     """mcn_env_state.hcount: env e shows only its first hcount[e] pedestrians to the policy.  Values must equal
     the reference network evaluated on the shorter list (attention sum, mean and distance test all ignore the

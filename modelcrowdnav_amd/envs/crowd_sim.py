@@ -59,6 +59,7 @@ class VecCrowdSim(object):
         self.human_num = None
         self.look_ahead_in_sim = False
         self.sim_world = None
+        self._sim_adapter = None
         self.human_policy_name = "orca"
         self._orca = policy_factory["orca"]()      # parameter carrier (orca.py:59-66)
         self._human_radius = self._human_v_pref = None
@@ -308,7 +309,15 @@ class VecCrowdSim(object):
         position + sim_world velocity * dt.  `sim_world` is a VecSGANWorld / VecTorchWorld style callable."""
         if self.sim_world is None:
             raise AttributeError("sim_world has to be set for look_ahead_in_sim")
-        new_v = self.sim_world(self.hpos)
+        sw = self.sim_world
+        if isinstance(sw, torch.nn.Module):
+            # the reference hands a bare MlpWorld / AttentionWorld module over (crowd_sim.py:684-688): evaluate it with
+            # its tensor convention for all E scenes; through torch, so that a module under training is always current
+            if self._sim_adapter is None or self._sim_adapter[0] is not sw:
+                from ..policy.world_model import VecTorchWorld
+                self._sim_adapter = (sw, VecTorchWorld(sw, self))
+            sw = self._sim_adapter[1]
+        new_v = sw(self.hpos)
         keep = self.count_hh
         self.count_hh = False
         try:
@@ -501,7 +510,21 @@ class CrowdSim(object):
         return torch.tensor([[action[0], action[1]]], dtype=torch.float64, device=self._vec.device)
 
     def onestep_lookahead(self, action):
-        return self.step(action, update=False)
+        """crowd_sim.py:325-329."""
+        if not self.look_ahead_in_sim:
+            return self.step(action, update=False)
+        return self.step_in_sim(action)
+
+    def step_in_sim(self, action):
+        """crowd_sim.py:633-696: the look-ahead whose humans are moved by the learned world model instead of ORCA --
+        same swept test / reward ladder, next human states = position + sim_world velocity * dt, nothing mutated."""
+        if self._vec.sim_world is None:
+            raise AttributeError("sim_world has to be set for look_ahead_in_sim")
+        self._in_sim = True
+        try:
+            return self.step(action, update=False)
+        finally:
+            self._in_sim = False
 
     def step(self, action, update=True):
         """crowd_sim.py:331-434."""
@@ -536,6 +559,8 @@ class CrowdSim(object):
         return out, reward, done, info_obj
 
     def _vec_step(self, actions, update):
+        if getattr(self, "_in_sim", False):
+            return self._vec.step_in_sim(actions)
         return self._vec.step(actions, update=update)
 
     def get_human_times(self, max_steps=8000):

@@ -397,6 +397,9 @@ class VecTorchWorld(object):
     def __call__(self, hpos, noise=None):
         env = self.env
         x = torch.cat([env.hpos, env.hvel], dim=2).reshape(env.num_envs, -1).float()
+        prm = next(self.module.parameters(), None)
+        if prm is not None and prm.device != x.device:          # a module left on the host (the E = 1 drivers do that)
+            x = x.to(prm.device)
         with torch.no_grad():
             v = self.module(x)
-        return v.view(env.num_envs, -1, 2).double().contiguous()
+        return v.view(env.num_envs, -1, 2).double().to(env.device).contiguous()

@@ -28,6 +28,9 @@
               actions / rewards / states, then get_human_times() to the end          (test.py:64-109, crowd_sim.py:219-258)
   g17_sarl_unicycle MultiHumanRL.predict with a unicycle robot ((v, r) actions, heading-dependent propagate, the theta
               feature): action_values + chosen action                  (cadrl.py:82-129,217-252, multi_human_rl.py:11-63)
+  g18_lookahead_in_sim CrowdSim with look_ahead_in_sim = true: SARL (query_env) evaluates every action through
+              env.onestep_lookahead -> step_in_sim, whose humans are moved by an MlpWorld module
+                                                                      (crowd_sim.py:325-329,633-696, multi_human_rl.py:37-38)
   g8_datagen  DataGen.gen_data_from_explore_in_mix on a synthetic recorded set: replay-then-freeze and
               replay-then-imagine (MlpWorld) samples, memory contents in IL and RL mode
                                                                       (datagen.py:379-543)
@@ -781,4 +784,44 @@ def g17_sarl_unicycle():
     print("g17_sarl_unicycle: %d arrays" % len(rec))
 
 
-FAMILIES = {"g17": g17_sarl_unicycle, "g16": g16_orca_robot, "g15": g15_explorer, "g14": g14_model_env, "g13": g13_world, "g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}
+def g18_lookahead_in_sim():
+    from crowd_sim.envs.utils.action import ActionXY
+    from crowd_nav.policy.world_model import MlpWorld
+    rec = {}
+    torch.manual_seed(18)
+    env, robot, pol = G.make_env("CrowdSim", robot_policy="sarl", humans_policy="orca", human_num=5)
+    pol.query_env = True
+    pol.set_env(env)
+    rec.update(_state_dict_arrays(pol.model, "w__"))
+    torch.manual_seed(180)
+    world = MlpWorld(5).eval()
+    with torch.no_grad():
+        for prm in world.parameters():
+            prm.mul_(1.5)
+    rec.update(_state_dict_arrays(world, "world__"))
+    env.look_ahead_in_sim = True
+    env.sim_world = world
+    env.device = torch.device("cpu")
+    for case in (1, 4):
+        ob = env.reset("test", case)
+        done, t = False, 0
+        A, V, R, I, LO, LR, LI = [], [], [], [], [], [], []
+        while not done and t < 20:
+            with torch.no_grad():
+                action = robot.act(ob)
+                lob, lr, ld, linfo = env.onestep_lookahead(ActionXY(0.3, -0.2))      # the env call on its own
+            V.append(np.array(pol.action_values, np.float64))
+            LO.append([[o.px, o.py, o.vx, o.vy, o.radius] for o in lob]); LR.append(lr); LI.append(G.info_code(linfo))
+            ob, reward, done, info = env.step(action)
+            A.append([action.vx, action.vy]); R.append(reward); I.append(G.info_code(info))
+            t += 1
+        key = "c%d_" % case
+        rec[key + "actions"], rec[key + "values"] = np.array(A), np.array(V)
+        rec[key + "rewards"], rec[key + "info"] = np.array(R), np.array(I)
+        rec[key + "look_obs"], rec[key + "look_reward"], rec[key + "look_info"] = np.array(LO), np.array(LR), np.array(LI)
+        print("  look_ahead_in_sim case %d: %d steps, outcome %d" % (case, t, I[-1]))
+    np.savez_compressed(os.path.join(OUT, "g18_lookahead_in_sim.npz"), **rec)
+    print("g18_lookahead_in_sim: %d arrays" % len(rec))
+
+
+FAMILIES = {"g18": g18_lookahead_in_sim, "g17": g17_sarl_unicycle, "g16": g16_orca_robot, "g15": g15_explorer, "g14": g14_model_env, "g13": g13_world, "g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}

@@ -353,6 +353,62 @@ def test_query_env_lookahead_matches_reference(visible, golden_dir):
         assert torch.equal(v1[0], values[e]) and int(b1[0]) == int(best[e])
 
 
+@pytest.mark.parametrize("world_on", ["cuda", "cpu"])
+def test_look_ahead_in_sim_matches_reference(world_on, golden_dir):
+    """g18_lookahead_in_sim.npz = the REAL reference's CrowdSim with `look_ahead_in_sim = true`: env.onestep_lookahead
+    goes to step_in_sim (crowd_sim.py:325-329,633-696), whose humans are moved by a bare MlpWorld module, and SARL with
+    `query_env` evaluates its 81 actions through it.  Per step: the look-ahead's observation / reward / info for one
+    fixed action, the 81 action values (1e-5), the chosen action; the real steps (ORCA humans) stay exact.  The module
+    may sit on the GPU or -- as the reference's drivers leave it -- on the host."""
+    import torch
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.envs import CrowdSim
+    from modelcrowdnav_amd.envs.utils.action import ActionXY
+    from modelcrowdnav_amd.envs.utils.robot import Robot
+    from modelcrowdnav_amd.policy.policy_factory import policy_factory
+    from modelcrowdnav_amd.policy.world_model import MlpWorld
+    g = np.load(os.path.join(golden_dir, "g18_lookahead_in_sim.npz"))
+    load = lambda pref: {k[len(pref):].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith(pref)}
+    cfg = configs.env_config()
+    env = CrowdSim()
+    env.configure(cfg)
+    robot = Robot(cfg, "robot")
+    pol = policy_factory["sarl"]()
+    pol.configure(configs.policy_config())
+    pol.kinematics = "holonomic"
+    pol.model.load_state_dict(load("w__"))
+    robot.set_policy(pol)
+    env.set_robot(robot)
+    pol.set_phase("test"); pol.set_device(torch.device("cuda", 0)); pol.set_env(env)
+    pol.query_env = True
+    world = MlpWorld(5)
+    world.load_state_dict(load("world__"))
+    world.eval().to(world_on)
+    env.reset("test", 0)
+    with pytest.raises(AttributeError):
+        env.look_ahead_in_sim = True
+        env.onestep_lookahead(ActionXY(0.0, 0.0))                     # no sim_world yet
+    env.sim_world = world
+    for case in (1, 4):
+        key = "c%d_" % case
+        ob = env.reset("test", case)
+        for t in range(len(g[key + "rewards"])):
+            action = robot.act(ob)
+            want_v = g[key + "values"][t]
+            np.testing.assert_allclose(np.array(pol.action_values), want_v, rtol=0, atol=1e-5, err_msg="%s step %d" % (key, t))
+            top2 = np.sort(want_v)[-2:]
+            if top2[1] - top2[0] > 2e-5:
+                assert (action.vx, action.vy) == tuple(g[key + "actions"][t]), (key, t)
+            before = [(h.px, h.py, h.vx, h.vy) for h in env.humans] + [env.global_time]
+            lob, lr, ld, linfo = env.onestep_lookahead(ActionXY(0.3, -0.2))
+            got = np.array([[o.px, o.py, o.vx, o.vy, o.radius] for o in lob])
+            np.testing.assert_allclose(got, g[key + "look_obs"][t], rtol=0, atol=2e-6)      # float32 module outputs
+            assert abs(lr - g[key + "look_reward"][t]) < 1e-12 and linfo.code == g[key + "look_info"][t], (key, t)
+            assert before == [(h.px, h.py, h.vx, h.vy) for h in env.humans] + [env.global_time]    # nothing mutated
+            ob, reward, done, info = env.step(ActionXY(*g[key + "actions"][t]))
+            assert reward == g[key + "rewards"][t] and info.code == g[key + "info"][t], (key, t)
+
+
 def test_model_crowd_sim_with_sgan_world(golden_dir):
     """BASELINE config 4 shape (reduced E): VecModelCrowdSim + VecSGANWorld + SARL robot; the env must move the
     humans exactly by the world model's velocities, and the E = 1 ModelCrowdSim view must agree with env 0."""

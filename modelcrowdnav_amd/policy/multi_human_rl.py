@@ -151,7 +151,11 @@ class MultiHumanRL(CADRL):
             vals = values[0].cpu().numpy()
             self.action_values = vals.tolist()
             idx = int(best.item())
-            self._last_attention = att[0, max(idx, 0)].cpu().numpy()
+            # the reference's model keeps the weights of its LAST forward, i.e. of the last candidate action
+            # (sarl.py:56,88-89), and that is what env.step stores per step; the chosen action's are kept beside them
+            a_host = att[0].cpu().numpy()
+            self._last_attention = a_host[-1].copy()
+            self.chosen_attention_weights = a_host[max(idx, 0)].copy()
             if idx < 0 or not np.isfinite(vals[idx]):
                 # every value NaN <=> `value > max_value` never fired in the reference loop
                 raise ValueError("Value network is not well trained. ")

@@ -134,6 +134,7 @@ class SARL(MultiHumanRL):
         super().__init__()
         self.name = "SARL"
         self._last_attention = None
+        self.chosen_attention_weights = None
 
     def configure(self, config):
         self.set_common_parameters(config)
@@ -158,6 +159,7 @@ class SARL(MultiHumanRL):
         return self._frags[1]
 
     def get_attention_weights(self):
-        """Attention over humans for the action chosen by the last predict() (sarl.py:88-89 reports the
-        weights of the last forward, i.e. of the last candidate action; here: of the chosen one)."""
+        """sarl.py:88-89: the attention weights of the model's last forward -- after predict() those of the LAST
+        candidate action of the table, as in the reference (stale after a call that returned without a look-ahead).
+        `chosen_attention_weights` holds the weights of the action predict() picked."""
         return self._last_attention

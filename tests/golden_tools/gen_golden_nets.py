@@ -752,7 +752,7 @@ def g17_sarl_unicycle():
     p.kinematics = "unicycle"
     rec.update(_state_dict_arrays(p.model, "w__"))
     for N in (5, 10, 2):
-        states, vals, acts = [], [], []
+        states, vals, acts, atts = [], [], [], []
         for s_ in range(40):
             rpx, rpy = rng.uniform(-3, 3, 2)
             near_goal = s_ % 8 == 7
@@ -775,6 +775,10 @@ def g17_sarl_unicycle():
                            np.array([[h.px, h.py, h.vx, h.vy, h.radius] for h in hs])))
             acts.append([act.v, act.r])
             vals.append(np.array(p.action_values) if not p.reach_destination(js) else np.full(81, np.nan))
+            # what env.step stores per step for rendering (crowd_sim.py:411-412): the weights of the LAST forward, i.e.
+            # of the last candidate action (sarl.py:56,88-89) -- stale where predict() returned early
+            atts.append(np.array(p.get_attention_weights(), np.float32))
+        rec["N%d_attention" % N] = np.array(atts)
         rec["N%d_self" % N] = np.array([s_[0] for s_ in states])
         rec["N%d_humans" % N] = np.array([s_[1] for s_ in states])
         rec["N%d_values" % N] = np.array(vals)

@@ -258,6 +258,21 @@ def test_unicycle_predict_matches_reference_fixture(N, golden_dir):
             assert tuple(actions[e]) == tuple(g["N%d_action" % N][e]), e
             checked += 1
     assert checked > 25
+    # the E = 1 surface on the same states: get_attention_weights() is what the reference's model holds after predict()
+    # -- the weights of the last candidate action (sarl.py:56,88-89), unchanged where predict() returned early
+    from modelcrowdnav_amd.envs.utils.state import FullState, ObservableState, JointState
+    prev = None
+    for e in range(0, E, 2):
+        js = JointState(FullState(*me[e].tolist()), [ObservableState(*row) for row in hum[e].tolist()])
+        act = pol.predict(js)
+        want = g["N%d_attention" % N][e]
+        if np.isnan(g["N%d_values" % N][e][0]):
+            assert tuple(act) == (0, 0)
+            assert prev is None or np.array_equal(pol.get_attention_weights(), prev)          # stale, as in the reference
+            continue
+        prev = pol.get_attention_weights()
+        np.testing.assert_allclose(prev, want, rtol=0, atol=TOL)
+        assert pol.chosen_attention_weights.shape == (N,) and abs(pol.chosen_attention_weights.sum() - 1) < 1e-5
 
 
 def test_per_env_pedestrian_counts():

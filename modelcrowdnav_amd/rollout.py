@@ -171,7 +171,13 @@ class VecExplorer(object):
             d = (mine[:, 1] - mine[:, 0]) % n_pool
             if not np.all(d == d[0]) or any(np.any((mine[:, r + 1] - mine[:, r]) % n_pool != d[0])
                                             for r in range(rounds - 1)):
-                raise NotImplementedError("non-uniform case stride (k wraps the case list unevenly)")
+                # the case list wraps unevenly (e.g. the counter starts near case_size): lay the pool out in episode
+                # order instead, one row per global episode -- then every env advances by exactly E_total rows
+                if device_scenarios is not None:
+                    raise NotImplementedError("device scenarios with a case list that wraps unevenly")
+                pool = pool[[slot_of[c] for c in cases]]
+                mine = np.array([[(lo + e) + r * E_total for r in range(rounds)] for e in range(E_local)])
+                d = np.array([E_total % (rounds * E_total)])
             stride = int(d[0])
         # at least two finished-episode slots: with one the kernel keeps the LATEST episode of an env (mcn.h), and an env
         # that finishes early keeps replaying its case until the slowest env is done -- with a stochastic robot

@@ -65,6 +65,28 @@ def test_vec_explorer_equals_sequential_loop():
     assert abs(got["danger_dist_sum"] - sum(w[4] for w in want)) < 1e-9
 
 
+def test_vec_explorer_case_counter_wraps_mid_run():
+    """The reference's counter wraps at case_size (crowd_sim.py:296): 20 validation episodes starting at case 90 of 100
+    play cases 90..99, 0..9 -- over 8 envs that is an uneven walk through the case list (3 rounds)."""
+    from modelcrowdnav_amd.envs import scenarios as S
+    from modelcrowdnav_amd.rollout import VecExplorer
+    E, N, k = 8, 5, 20
+    env = H.make_vec_env(E, N)
+    env.track_human_times = False; env.export_human_actions = False
+    assert env.case_size["val"] == 100
+    env.case_counter["val"] = 90
+    ex = VecExplorer(env, env.robot, gamma=0.9, policy=object())
+    avg, sr, cr, tr = ex.run_k_episodes(k, "val", action_fn=_goal_seeking)
+    cases = [(90 + i) % 100 for i in range(k)]
+    want = [_oracle_episode(S.scenario_for_case(env.spec(), "val", c, N, "circle_crossing")) for c in cases]
+    got = ex.last_records
+    assert got["infos"] == [w[1] for w in want]
+    assert got["returns"] == [w[0] for w in want] and got["times"] == [w[2] for w in want]
+    assert avg == sum(w[0] for w in want) / k
+    assert env.case_counter["val"] == 10
+    assert got["danger_steps"] == sum(w[3] for w in want)
+
+
 def test_vec_explorer_action_sequence_uses_fused_rollout():
     """A pre-drawn action sequence run through mcn_env_rollout chunks gives the records of the per-step loop."""
     import torch

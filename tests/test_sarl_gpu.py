@@ -201,6 +201,39 @@ def test_rewards_are_float64_exact():
     assert np.array_equal(values.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("speeds,rotations", [(3, 8), (7, 12), (1, 1)])
+def test_other_action_space_sizes(speeds, rotations):
+    """policy.config [action_space] speed_samples / rotation_samples (cadrl.py:82-102): the table has
+    speeds * rotations + 1 rows -- 25, 85 and 2 here instead of the shipped 81 -- and the kernels take A as an argument
+    ((env, action) pairs are tiled 16 at a time whatever A is)."""
+    import torch
+    rng = np.random.RandomState(speeds * 100 + rotations)
+    E, N = 21, 5
+    pol = _policy(seed=6)
+    pol.speed_samples, pol.rotation_samples = speeds, rotations
+    pol.action_space = None
+    env = H.make_vec_env(E, N)
+    st = H.random_state(rng, E, N, randomize=True)
+    H.upload(env, st)
+    actions, best, values = pol.predict_batch(env, want_values=True)
+    values, best, actions = values.cpu().numpy(), best.cpu().numpy(), actions.cpu().numpy()
+    table = pol._action_table
+    A = speeds * rotations + 1
+    assert table.shape == (A, 2) and values.shape == (E, A)
+    w = {k: v.detach().cpu() for k, v in pol.model.state_dict().items()}
+    for e in range(0, E, 3):
+        row = [st.rpx[e], st.rpy[e], st.rvx[e], st.rvy[e], st.rr[e], st.rgx[e], st.rgy[e], 1.0, 0.0]
+        hum = np.stack([st.hpx[e], st.hpy[e], st.hvx[e], st.hvy[e], st.hr[e]], 1)
+        if np.hypot(row[5] - row[0], row[6] - row[1]) < row[4]:
+            assert best[e] == -1 and tuple(actions[e]) == (0.0, 0.0)
+            continue
+        ref, idx = pyref.sarl_predict(w, row, hum, table)
+        np.testing.assert_allclose(values[e], ref, rtol=0, atol=TOL)
+        top2 = np.sort(ref)[-2:]
+        if A == 2 or top2[1] - top2[0] > 2 * TOL:
+            assert best[e] == idx and tuple(actions[e]) == tuple(table[idx])
+
+
 def test_unicycle_lookahead_matches_oracle():
     """(v, r) action table, heading-dependent propagate and the theta feature (cadrl.py:97-99,118-124,236-237)."""
     import torch

@@ -132,12 +132,23 @@ class SGANWorld(nn.Module):
             data = self._read_cache()
             frames = np.unique(data[:, 0])[-8:] if len(data) else []
             if len(frames) == 8:
-                hist = np.zeros((1, 8, n_humans, 2))
+                hist = np.full((1, 8, n_humans, 2), np.nan)
                 for t, f in enumerate(frames):
                     sel = data[data[:, 0] == f]
                     for row in sel:
                         if int(row[1]) < n_humans:
                             hist[0, t, int(row[1])] = row[2:4]
+                # a pedestrian that enters after the first frame / leaves before the last one stands on its first /
+                # last recorded position for the missing frames (world_model.py:166-180)
+                for p_ in range(n_humans):
+                    seen = np.nonzero(~np.isnan(hist[0, :, p_, 0]))[0]
+                    if len(seen) == 0:
+                        hist[0, :, p_] = 0.0
+                        continue
+                    hist[0, :seen[0], p_] = hist[0, seen[0], p_]
+                    hist[0, seen[-1] + 1:, p_] = hist[0, seen[-1], p_]
+                if np.isnan(hist).any():
+                    raise NotImplementedError("a pedestrian with a gap inside the cached window")
                 self._vec.reset_history(torch.from_numpy(hist))
                 return
         self._vec = None

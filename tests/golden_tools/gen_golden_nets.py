@@ -31,6 +31,8 @@
   g18_lookahead_in_sim CrowdSim with look_ahead_in_sim = true: SARL (query_env) evaluates every action through
               env.onestep_lookahead -> step_in_sim, whose humans are moved by an MlpWorld module
                                                                       (crowd_sim.py:325-329,633-696, multi_human_rl.py:37-38)
+  g19_sganworld the E = 1 SGANWorld callable (world_model.py:134-268) on a cache file: rolling 8-frame history, positions
+              rounded to 1e-4, late pedestrians padded, generator noise from torch's global stream (seeded per call)
   g8_datagen  DataGen.gen_data_from_explore_in_mix on a synthetic recorded set: replay-then-freeze and
               replay-then-imagine (MlpWorld) samples, memory contents in IL and RL mode
                                                                       (datagen.py:379-543)
@@ -828,4 +830,43 @@ def g18_lookahead_in_sim():
     print("g18_lookahead_in_sim: %d arrays" % len(rec))
 
 
-FAMILIES = {"g18": g18_lookahead_in_sim, "g17": g17_sarl_unicycle, "g16": g16_orca_robot, "g15": g15_explorer, "g14": g14_model_env, "g13": g13_world, "g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}
+def g19_sganworld():
+    import tempfile
+    from crowd_nav.policy.world_model import SGANWorld
+    rng = np.random.RandomState(19)
+    rec = {}
+    for fam, tag in (("sgan-p-models", "p"), ("sgan-models", "np")):
+        for case, (N, late) in enumerate(((5, False), (3, True), (10, False))):
+            with tempfile.TemporaryDirectory() as d:
+                path = os.path.join(d, "generate.txt")
+                pos0 = rng.uniform(-4, 4, (N, 2)); vel0 = rng.uniform(-0.8, 0.8, (N, 2))
+                lines = []
+                for f in range(8):                                     # frames 11..18, 0.25 s apart
+                    for p_ in range(N):
+                        if late and p_ == N - 1 and f < 3:
+                            continue                                   # the last pedestrian enters at the 4th frame
+                        x, y = pos0[p_] + vel0[p_] * 0.25 * (f - 7) + rng.normal(0, 0.01, 2)
+                        lines.append("%s\t%s\t%s\t%s\n" % (11 + f, p_, x, y))
+                open(path, "w").write("".join(lines))
+                key = "%s_c%d_" % (tag, case)
+                rec[key + "cache0"] = np.array("".join(lines))
+                world = SGANWorld(path, torch.device("cpu"), obs_len=8, time_step=0.25,
+                                  pretrainPath=os.path.join(REF, "sgan", "models", fam, "zara1_8_model.pt"))
+                # the state the env hands over: positions continue the recorded motion
+                last = np.array([[float(v) for v in ln.split("\t")[2:4]] for ln in lines if ln.startswith("18\t")])
+                pos, vel = last + vel0 * 0.25, vel0.copy()
+                ins, outs = [], []
+                for step in range(7):
+                    torch.manual_seed(1900 + step)
+                    in_state = [[pos[i, 0], pos[i, 1], vel[i, 0], vel[i, 1]] for i in range(N)]
+                    v = np.asarray(world(in_state), np.float64)
+                    ins.append(in_state); outs.append(v)
+                    pos, vel = pos + v * 0.25, v
+                rec[key + "in"], rec[key + "out"] = np.array(ins), np.array(outs)
+                rec[key + "cache_end"] = np.array(open(path).read())
+            print("  %s case %d: N %d late %s, |v| up to %.3f" % (tag, case, N, late, np.abs(outs).max()))
+    np.savez_compressed(os.path.join(OUT, "g19_sganworld.npz"), **rec)
+    print("g19_sganworld: %d arrays" % len(rec))
+
+
+FAMILIES = {"g19": g19_sganworld, "g18": g18_lookahead_in_sim, "g17": g17_sarl_unicycle, "g16": g16_orca_robot, "g15": g15_explorer, "g14": g14_model_env, "g13": g13_world, "g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}

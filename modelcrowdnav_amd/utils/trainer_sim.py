@@ -56,8 +56,10 @@ class Trainer_Sim(object):
 
     def _pairs(self):
         rows = self.memory.memory if hasattr(self.memory, "memory") else self.memory
-        rows = list(rows)
-        random.shuffle(rows)                                    # trainer_sim.py:55 (Python's RNG, like the reference)
+        if not isinstance(rows, list):
+            rows = list(rows)
+        random.shuffle(rows)            # trainer_sim.py:55: Python's RNG, and IN PLACE -- the memory itself is reordered,
+        #                                 so a second call splits what the first one left
         n_train = int(len(rows) * self.train_size)
 
         def stack(part):
@@ -70,8 +72,10 @@ class Trainer_Sim(object):
             return cur.reshape(cur.shape[0], -1), nxt.reshape(nxt.shape[0], -1)
         return stack(rows[:n_train]), stack(rows[n_train:])
 
-    def optimize_epoch(self, num_epochs, reset=False):
-        """trainer_sim.py:48-110.  Returns the best validation loss."""
+    def optimize_epoch(self, num_epochs, reset=False, perms=None):
+        """trainer_sim.py:48-110.  Returns the best validation loss.
+        perms (optional): (train [num_epochs][n_train], validation [num_epochs][n_val]) row orders that replace the
+        shuffles drawn here -- the reference's two DataLoaders draw theirs from torch's global generator."""
         if self.optimizer is None:
             raise ValueError("Learning rate is not set!")
         (tx, ty), (vx, vy) = self._pairs()
@@ -82,9 +86,13 @@ class Trainer_Sim(object):
         if reset:
             es.best_score = None
         B = self.batch_size
-        for _ in range(num_epochs):
+        for ep in range(num_epochs):
             self.model.train()
-            perm = torch.randperm(tx.shape[0], device=tx.device)
+            if perms is None:
+                perm = torch.randperm(tx.shape[0], device=tx.device)
+            else:
+                perm = torch.as_tensor(perms[0][ep], dtype=torch.long, device=tx.device)
+                vperm = torch.as_tensor(perms[1][ep], dtype=torch.long, device=vx.device)
             for i in range(0, tx.shape[0], B):
                 idx = perm[i:i + B]
                 loss = self.criterion(self.model(tx[idx]), ty[idx])
@@ -93,7 +101,8 @@ class Trainer_Sim(object):
                 self.optimizer.step()
             self.model.eval()
             with torch.no_grad():
-                losses = [self.criterion(self.model(vx[i:i + B]), vy[i:i + B]).item() for i in range(0, vx.shape[0], B)]
+                ex, ey = (vx, vy) if perms is None else (vx[vperm], vy[vperm])
+                losses = [self.criterion(self.model(ex[i:i + B]), ey[i:i + B]).item() for i in range(0, ex.shape[0], B)]
             es(sum(losses) / len(losses), self.model)
             if es.early_stop:
                 break

@@ -33,6 +33,8 @@
                                                                       (crowd_sim.py:325-329,633-696, multi_human_rl.py:37-38)
   g19_sganworld the E = 1 SGANWorld callable (world_model.py:134-268) on a cache file: rolling 8-frame history, positions
               rounded to 1e-4, late pedestrians padded, generator noise from torch's global stream (seeded per call)
+  g20_trainer_sim Trainer_Sim.optimize_epoch (Adam, MSE, 80 / 20 split after random.shuffle, early stopping, best weights
+              restored, model.mse) on a seeded AttentionWorld with one batch per epoch    (trainer_sim.py:26-110)
   g8_datagen  DataGen.gen_data_from_explore_in_mix on a synthetic recorded set: replay-then-freeze and
               replay-then-imagine (MlpWorld) samples, memory contents in IL and RL mode
                                                                       (datagen.py:379-543)
@@ -869,4 +871,86 @@ def g19_sganworld():
     print("g19_sganworld: %d arrays" % len(rec))
 
 
-FAMILIES = {"g19": g19_sganworld, "g18": g18_lookahead_in_sim, "g17": g17_sarl_unicycle, "g16": g16_orca_robot, "g15": g15_explorer, "g14": g14_model_env, "g13": g13_world, "g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}
+def g20_trainer_sim():
+    """The reference's world-model trainer made reproducible: AttentionWorld has no dropout, so the only random inputs are
+    `random.shuffle(memory)` before the 80 / 20 split (trainer_sim.py:55; Python's generator, seeded here) and the two
+    DataLoaders' shuffles, which draw from torch's global generator -- recorded by replaying identical DataLoaders over
+    row indices from the same generator state (they consume it exactly as the trainer's).
+    pytorchtools.py:25 reads `np.Inf`, an alias numpy 2.x removed: restored in this tool process only."""
+    import random
+    import tempfile
+    import torch.utils.data as tud
+    from crowd_sim.envs.utils.state import JointState  # noqa: F401
+    from crowd_nav.policy.world_model import AttentionWorld
+    from crowd_nav.utils.trainer_sim import Trainer_Sim
+    from crowd_nav.utils.memory import ReplayMemory
+    if not hasattr(np, "Inf"):
+        np.Inf = np.inf
+    rng = np.random.RandomState(20)
+    rec = {}
+    N, rows = 5, 240
+    cur = rng.uniform(-3, 3, (rows, N, 4)).astype(np.float32)
+    nxt = (0.8 * cur[:, :, 2:4] + 0.05 * np.tanh(cur[:, :, 0:2])).astype(np.float32)        # a smooth law to fit
+    rec["cur"], rec["next"] = cur, nxt
+
+    class _Rows(tud.Dataset):
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            return i
+
+    def replay(n_train, n_val, epochs):
+        tl, vl = tud.DataLoader(_Rows(n_train), 1000, shuffle=True), tud.DataLoader(_Rows(n_val), 1000, shuffle=True)
+        tp, vp = [], []
+        for _ in range(epochs):
+            tp.append(np.concatenate([b.numpy() for b in tl]).astype(np.int64))
+            vp.append(np.concatenate([b.numpy() for b in vl]).astype(np.int64))
+        return np.stack(tp), np.stack(vp)
+    # "stop": 30 rows whose validation part (known: the same seeded shuffle of a 30-element list) carries the NEGATED law --
+    # the better the training part is fitted, the worse the validation loss: best = first epoch, stop after 7 more
+    order = list(range(30))
+    random.seed(2000)
+    random.shuffle(order)
+    nxt_stop = nxt[:30].copy()
+    nxt_stop[order[24:]] *= -1.0
+    rec["next_stop"] = nxt_stop
+    for tag, calls, lr, use in (("short", (5, 3), 1e-3, rows), ("stop", (50,), 1e-3, 30)):
+        torch.manual_seed(200)
+        model = AttentionWorld()
+        if tag == "short":
+            rec.update(_state_dict_arrays(model, "w0__"))
+        mem = ReplayMemory(10000)
+        for i in range(use):
+            mem.push((torch.from_numpy(cur[i]), torch.from_numpy((nxt if tag == "short" else nxt_stop)[i])))
+        n_train = int(use * 0.8)
+        with tempfile.TemporaryDirectory() as d:
+            tr = Trainer_Sim(model, mem, torch.device("cpu"), 1000, os.path.join(d, "checkpoint.pt"))
+            tr.set_learning_rate(lr)
+            random.seed(2000)
+            torch.manual_seed(201)
+            state = torch.get_rng_state()
+            bests = [tr.optimize_epoch(e) for e in calls]            # a second call keeps the best score
+        torch.set_rng_state(state)
+        for c, e in enumerate(calls):
+            tp, vp = replay(n_train, use - n_train, e)
+            rec["%s_call%d_train_perms" % (tag, c)], rec["%s_call%d_val_perms" % (tag, c)] = tp, vp
+        rec[tag + "_best"] = np.array(bests, np.float64)
+        rec[tag + "_mse"] = np.array(model.mse, np.float64)
+        rec[tag + "_counter"] = np.array(tr.early_stopping.counter)
+        rec[tag + "_stopped"] = np.array(bool(tr.early_stopping.early_stop))
+        rec[tag + "_rows"] = np.array(use)
+        w1 = _state_dict_arrays(model, tag + "_w1__")
+        if tag == "stop":                                   # the small layers are enough to tell the restored weights
+            w1 = {k_: v_ for k_, v_ in w1.items() if "mlp3__6" in k_ or "mlp1__0" in k_ or "attention__4" in k_}
+        rec.update(w1)
+        print("  %s: best %s, mse %.6g, counter %d, stopped %s" % (tag, bests, model.mse, tr.early_stopping.counter,
+                                                                 tr.early_stopping.early_stop))
+    np.savez_compressed(os.path.join(OUT, "g20_trainer_sim.npz"), **rec)
+    print("g20_trainer_sim: %d arrays" % len(rec))
+
+
+FAMILIES = {"g20": g20_trainer_sim, "g19": g19_sganworld, "g18": g18_lookahead_in_sim, "g17": g17_sarl_unicycle, "g16": g16_orca_robot, "g15": g15_explorer, "g14": g14_model_env, "g13": g13_world, "g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}

@@ -266,6 +266,61 @@ def test_world_model_modules_match_reference_outputs(case, golden_dir):
         np.testing.assert_allclose(np.asarray(m.attention_weights), g[case + "_weights0"], rtol=0, atol=1e-6)
 
 
+def test_world_model_trainer_matches_reference_trainer(golden_dir, tmp_path):
+    """g20_trainer_sim.npz = the reference's own Trainer_Sim (trainer_sim.py:26-110) on a seeded AttentionWorld (no
+    dropout): `random.shuffle(memory)` (Python's generator, seeded; in place, so a second call splits what the first
+    left) decides the 80 / 20 split, the DataLoaders' row orders are the recorded ones.  5 + 3 epochs (the second call
+    keeps the best score), and a 30-row run whose validation rows carry the negated law, so that it stops after
+    patience + 1 epochs with the first epoch's weights: best validation
+    losses, `model.mse`, early-stopping state and the restored best weights."""
+    import random
+    from modelcrowdnav_amd.policy.world_model import AttentionWorld
+    from modelcrowdnav_amd.utils.trainer_sim import Trainer_Sim
+    g = np.load(os.path.join(golden_dir, "g20_trainer_sim.npz"))
+    load = lambda pref: {k[len(pref):].replace("__", "."): torch.from_numpy(g[k]) for k in g.files if k.startswith(pref)}
+
+    class Memory(object):                      # what the trainer needs of crowd_nav.utils.memory.ReplayMemory
+        def __init__(self):
+            self.memory = []
+
+        def __len__(self):
+            return len(self.memory)
+    RT = {"short": 2e-5, "stop": 2e-5}
+    for tag, calls, lr in (("short", (5, 3), 1e-3), ("stop", (50,), 1e-3)):
+        model = AttentionWorld()
+        model.load_state_dict(load("w0__"))
+        mem = Memory()
+        nxt = g["next"] if tag == "short" else g["next_stop"]      # "stop": the validation rows carry the negated law
+        for i in range(int(g[tag + "_rows"])):
+            mem.memory.append((torch.from_numpy(g["cur"][i]), torch.from_numpy(nxt[i])))
+        tr = Trainer_Sim(model, mem, torch.device("cpu"), 1000, str(tmp_path / (tag + ".pt")))
+        tr.set_learning_rate(lr)
+        random.seed(2000)
+        bests = [tr.optimize_epoch(e, perms=(g["%s_call%d_train_perms" % (tag, c)], g["%s_call%d_val_perms" % (tag, c)]))
+                 for c, e in enumerate(calls)]
+        # same ops on the same rows in the same order on the same kind of machine: 1e-6 relative leaves room for a
+        # differently blocked GEMM
+        np.testing.assert_allclose(bests, g[tag + "_best"], rtol=RT[tag], atol=0)
+        assert abs(model.mse - float(g[tag + "_mse"])) <= RT[tag] * float(g[tag + "_mse"])
+        assert tr.early_stopping.counter == int(g[tag + "_counter"])
+        assert bool(tr.early_stopping.early_stop) == bool(g[tag + "_stopped"])
+        want = load(tag + "_w1__")
+        assert len(want) >= 6
+        sd = model.state_dict()
+        worst = max(float((sd[k] - v).abs().max()) for k, v in want.items())
+        # Adam turns a gradient that is only rounding noise (dead ReLU units, the near-uniform attention branch) into
+        # steps of size lr: single weights are determined to lr x steps, the function they compute much better
+        assert worst <= lr * sum(calls), (tag, worst)
+        if tag == "short":
+            ref = AttentionWorld()
+            ref.load_state_dict(want)
+            x = torch.from_numpy(g["cur"][:64]).reshape(64, -1)
+            with torch.no_grad():
+                d = float((model(x) - ref(x)).abs().max())
+            assert d <= 1e-4, d
+    assert bool(g["stop_stopped"]) and int(g["stop_counter"]) == 7 and len(g["short_best"]) == 2
+
+
 def test_world_model_trainer_early_stopping_and_best_weights(tmp_path):
     """Trainer_Sim (trainer_sim.py:26-110): fits MlpWorld to a synthetic 'next velocity = damped current velocity'
     law, returns the best validation loss, restores the best weights and records model.mse."""

@@ -35,6 +35,8 @@
               rounded to 1e-4, late pedestrians padded, generator noise from torch's global stream (seeded per call)
   g20_trainer_sim Trainer_Sim.optimize_epoch (Adam, MSE, 80 / 20 split after random.shuffle, early stopping, best weights
               restored, model.mse) on a seeded AttentionWorld with one batch per epoch    (trainer_sim.py:26-110)
+  g21_epsilon MultiHumanRL.predict in the train phase with epsilon 0.5: numpy's global stream decides exploration and the random
+              action (multi_human_rl.py:27-29), `last_state` is kept (:60-61)
   g8_datagen  DataGen.gen_data_from_explore_in_mix on a synthetic recorded set: replay-then-freeze and
               replay-then-imagine (MlpWorld) samples, memory contents in IL and RL mode
                                                                       (datagen.py:379-543)
@@ -953,4 +955,37 @@ def g20_trainer_sim():
     print("g20_trainer_sim: %d arrays" % len(rec))
 
 
-FAMILIES = {"g20": g20_trainer_sim, "g19": g19_sganworld, "g18": g18_lookahead_in_sim, "g17": g17_sarl_unicycle, "g16": g16_orca_robot, "g15": g15_explorer, "g14": g14_model_env, "g13": g13_world, "g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}
+def g21_epsilon():
+    from crowd_sim.envs.utils.state import FullState, ObservableState, JointState
+    rng = np.random.RandomState(21)
+    p = _sarl_policy(17)                         # the weights g17_sarl_unicycle.npz already holds
+    g17 = np.load(os.path.join(OUT, "g17_sarl_unicycle.npz"))
+    assert all(np.array_equal(v, g17[k]) for k, v in _state_dict_arrays(p.model, "w__").items())
+    p.kinematics = "holonomic"
+    p.set_phase("train")
+    p.set_epsilon(0.5)
+    N = 5
+    selfs, hums, acts, lasts, explored = [], [], [], [], []
+    np.random.seed(2100)
+    for s_ in range(60):
+        rpx, rpy = rng.uniform(-3, 3, 2)
+        gx, gy = (rpx + 0.1, rpy - 0.1) if s_ % 15 == 14 else rng.uniform(-4, 4, 2)
+        me = FullState(rpx, rpy, rng.uniform(-1, 1), rng.uniform(-1, 1), 0.3, gx, gy, 1.0, 0.0)
+        hs = [ObservableState(*rng.uniform(-4, 4, 2), rng.uniform(-1, 1), rng.uniform(-1, 1), 0.3) for _ in range(N)]
+        js = JointState(me, hs)
+        p.action_values = None
+        with torch.no_grad():
+            act = p.predict(js)
+        selfs.append([me.px, me.py, me.vx, me.vy, me.radius, me.gx, me.gy, me.v_pref, me.theta])
+        hums.append([[h.px, h.py, h.vx, h.vy, h.radius] for h in hs])
+        acts.append([act.vx, act.vy])
+        lasts.append(p.last_state.numpy().copy())
+        # 0: greedy (the look-ahead ran), 1: a random table row, 2: the robot stands on its goal (no draw at all)
+        explored.append(2 if p.reach_destination(js) else int(p.action_values is None))
+    rec = dict(selfs=np.array(selfs), humans=np.array(hums), actions=np.array(acts), last_states=np.array(lasts),
+               explored=np.array(explored), table=np.array([[a.vx, a.vy] for a in p.action_space]))
+    np.savez_compressed(os.path.join(OUT, "g21_epsilon.npz"), **rec)
+    print("g21_epsilon: %d arrays; greedy / random / at goal: %s" % (len(rec), np.bincount(np.array(explored))))
+
+
+FAMILIES = {"g21": g21_epsilon, "g20": g20_trainer_sim, "g19": g19_sganworld, "g18": g18_lookahead_in_sim, "g17": g17_sarl_unicycle, "g16": g16_orca_robot, "g15": g15_explorer, "g14": g14_model_env, "g13": g13_world, "g10": g10_trainer, "g11": g11_queryenv, "g12": g12_update_memory, "g5": g5_sarl, "g6": g6_sgan, "g7": g7_episode, "g8": g8_datagen, "g9": g9_realdata}

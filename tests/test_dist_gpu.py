@@ -96,3 +96,24 @@ def test_bench_collective_branches_on_rccl():
     assert line["n_gpus"] == 1 and line["collective"] == "nccl"
     assert line["gathered_episode_records"] is not None and line["gathered_episode_records"] >= 0
     assert line["value"] > 1e6
+
+
+def test_bench_two_ranks_through_the_drivers_launcher():
+    """The driver's own command line for N = 2 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...` -- rehearsed on this one-GPU box: both ranks share
+    GPU 0 and the collectives run on gloo (MCN_BENCH_BACKEND), everything else is the path the 8-GPU node takes:
+    rank / local-rank from the launcher's environment, one JSON line from rank 0, whole-job value over both ranks,
+    episode records of both shards gathered."""
+    port = 35100 + (os.getpid() % 2000)
+    out = _run_child([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                      "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "20",
+                      "--warmup", "5", "--no-sweep", "--no-extra", "--no-cpu-baseline", "--min-timed-ms", "5"],
+                     timeout=600, env_extra={"MCN_BENCH_BACKEND": "gloo"})
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]                      # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["warmup"] == 5 and line["scaling"] == "weak"
+    assert line["collective"] == "gloo" and line["config"]["envs_per_gpu"] == 4096
+    assert "x2" in line["config"]["parallelism"]
+    assert line["gathered_episode_records"] is not None and line["gathered_episode_records"] > 0
+    assert line["value"] > 1e8 and line["cpu_baseline"] is None

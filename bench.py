@@ -161,15 +161,21 @@ def classify_kernel(name, run_humans=None):
         return fam, int(args[0]), "orca", 8 if args[2] == "true" else 4
     if fam == "env_rollout_quad_kernel":
         return fam, int(args[0]), "orca", 8 if args[3] == "true" else 4
+    if fam == "env_step_loop_kernel":                 # <NT, VIS>: the one-wavefront ORCA step run T times in one launch
+        return fam, int(args[0]), "orca", 1
     return fam, run_humans, None, None
 
 
 def expected_kernel(E, N, given, steps_per_launch=1):
     """The kernel family the library's dispatcher picks for this launch (csrc/mcn_api.hip fill_step_params,
     env_step.hip launch_env_step, automatic tuning)."""
-    if steps_per_launch > 1:
-        return "env_rollout_quad_kernel"
     waves = -(-E // (64 // N))
+    if steps_per_launch > 1:
+        if N - 1 <= 4:
+            return "env_rollout_quad_kernel"
+        # 6-10 humans: mcn_env_rollout runs the one-wavefront step kernel T times inside one launch while the batch is
+        # latency-bound (env_step.hip launch_env_step_loop), else T launches of the step kernel
+        return "env_step_loop_kernel" if (N <= 10 and waves <= (12288 if N - 1 >= 8 else 4096)) else "env_step_kernel"
     if given:
         return "env_pair_kernel" if (waves > 4096 and N in (5, 10)) else "env_step_kernel"
     if N - 1 <= 4 and -(-E // (64 // (4 * N))) <= 2800:
@@ -419,17 +425,34 @@ def extra_configs(device):
                     "roofline": _sgan_roofline(E, N, ms_sgan)})
         del env
     # ---- config 5's per-GPU shard: 4096 envs x 10 humans, ORCA humans, random robot actions ----
-    # (BASELINE configs[4] = 32 768 x 10 over 8 GPUs; crowds above 5 humans have no fused multi-step kernel: one
-    # mcn_env_step launch per step, replayed from a hipGraph)
-    E, N = 4096, 10
+    # (BASELINE configs[4] = 32 768 x 10 over 8 GPUs.  As in the headline, the pre-drawn actions are known up front, so
+    # the steps go to the device as mcn_env_rollout launches of T steps: for 6-10 humans that is the one-wavefront step
+    # kernel run T times inside one launch, env_step_loop_kernel.  One mcn_env_step launch per step -- what a
+    # policy-in-the-loop caller gets -- is reported beside it.)
+    E, N, T10 = 4096, 10, 500
     env, _ = build_env(E, N, 0, device)
     acts10 = make_actions(64, E, E, 0, device)
     ms10, _best = time_kernel_events(env, acts10, 200)
+    seq10 = make_actions(T10, E, E, 0, device)
+    env.rollout(seq10[:50])
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(4):
+        env.rollout(seq10)
+    ev[1].record()
+    torch.cuda.synchronize()
+    ms10r = ev[0].elapsed_time(ev[1]) / 4                        # one launch = T10 steps
     out.append({"config": "4096 envs x 10 humans per GPU (the shard of BASELINE's 32 768 x 10 on 8 GPUs), ORCA humans, "
-                          "random robot actions, one mcn_env_step launch per step",
-                "ms_per_step": round(ms10, 5), "env_steps_per_sec": round(E / ms10 * 1e3, 1),
-                "roofline": roofline_entry(E, N, ms10),
-                "roofline_valu": valu_roofline(E, N, ms10, 1, rollout=False)})
+                          "random robot actions, %d steps per mcn_env_rollout launch" % T10,
+                "ms_per_step": round(ms10r / T10, 5), "env_steps_per_sec": round(E * T10 / ms10r * 1e3, 1),
+                "steps_per_launch": T10,
+                "roofline": roofline_entry(E, N, ms10r, steps_per_launch=T10),
+                "roofline_valu": valu_roofline(E, N, ms10r, T10, rollout=True),
+                "single_step_launch": {"mode": "one mcn_env_step launch per step, hipGraph of 200",
+                                       "ms_per_step": round(ms10, 5), "env_steps_per_sec": round(E / ms10 * 1e3, 1),
+                                       "roofline": roofline_entry(E, N, ms10),
+                                       "roofline_valu": valu_roofline(E, N, ms10, 1, rollout=False)}})
     del env
     # ---- config 5's WHOLE batch on one GPU: 32 768 envs x 10 humans (what a node with one MI355X would run) ----
     E = 32768

@@ -50,9 +50,11 @@ struct GroupCand {
 // MODE: MCN_HUMANS_* fixed at compile time, so the given-velocity / linear variants carry no ORCA registers,
 // no neighbour staging and no goal loads (they are pure streaming kernels and want maximum occupancy).
 // HH_T: 0 never count overlaps, 1 always, 2 decide at run time from cfg.count_hh.
+// One env step for the workgroup's env slots: everything between the state in HBM before the step and after it.  A
+// device function so that two kernels can share it: env_step_kernel (one step per launch) and env_step_loop_kernel
+// (T steps per launch for the one-wavefront form, below).
 template <int BLOCK, int NT, int VIS, int MODE, int HH_T>
-__global__ __launch_bounds__(BLOCK)     // (occupancy hints spill: 5 / 6 workgroups per CU on the 5-human ORCA kernel 203 -> 320 / 485 us at 2^20 envs)
-void env_step_kernel(const StepParams p)
+__device__ __forceinline__ void env_step_body(const StepParams &p)
 {
     constexpr bool kStageHumans = (MODE == MCN_HUMANS_ORCA) || (HH_T != 0);
 #ifdef MCN_DIAG
@@ -453,6 +455,31 @@ void env_step_kernel(const StepParams p)
     }
 }
 
+template <int BLOCK, int NT, int VIS, int MODE, int HH_T>
+__global__ __launch_bounds__(BLOCK)     // (occupancy hints spill: 5 / 6 workgroups per CU on the 5-human ORCA kernel 203 -> 320 / 485 us at 2^20 envs)
+void env_step_kernel(const StepParams p)
+{
+    env_step_body<BLOCK, NT, VIS, MODE, HH_T>(p);
+}
+
+// T consecutive steps in ONE launch for the crowds the quad-parallel rollout kernel does not cover (6-10 humans) in
+// latency-bound batches: the one-wavefront workgroup simply runs the step T times, taking step t's actions from
+// actions[t][E][2].  Every value a step reads back was written by the same lane of the same wavefront one iteration
+// earlier (each lane owns its human, the leader lane its robot / clock / rollout record), so program order is all the
+// ordering that is needed; the state goes through L2 instead of registers, but the T - 1 launch gaps (4-6 us each
+// at 4096 envs, where a step takes ~23 us) and the cold first touches disappear.  Same arithmetic, same stores, same
+// order as T launches of env_step_kernel<64, ...>: bit-identical by construction.
+template <int NT, int VIS>
+__global__ __launch_bounds__(64) void env_step_loop_kernel(StepParams p, const int T)
+{
+    const double *acts = p.actions;
+    for (int t = 0; t < T; ++t) {
+        p.actions = acts + (size_t)t * (size_t)p.E * 2;
+        env_step_body<64, NT, VIS, MCN_HUMANS_ORCA, 2>(p);
+        __syncthreads();                       // the next step restages the LDS tiles this one still reads
+    }
+}
+
 // The deferred 3-D LPs of one step (lp3_queue.hpp).  Finishes each parked solve exactly as the step kernel would have
 // (same sorted half-planes, same running result) and then does for that human what the step kernel skipped: the
 // exported action, and -- by the flag the step kernel left -- the integration (crowd_sim.py:416-421) or the look-ahead
@@ -602,6 +629,32 @@ static void dispatch(const StepParams &p, int blocks, hipStream_t stream)
         if (p.cfg.count_hh) launch_one<BLOCK, 0, 0, MCN_HUMANS_LINEAR, 1>(p, blocks, stream);
         else                launch_one<BLOCK, 0, 0, MCN_HUMANS_LINEAR, 0>(p, blocks, stream);
     }
+}
+
+// mcn_env_rollout for 6-10 ORCA humans in a latency-bound batch: one env_step_loop_kernel launch instead of T step
+// launches.  false = not applicable (the caller falls back to T launches).
+bool launch_env_step_loop(const StepParams &p, int T, hipStream_t stream)
+{
+    if (p.cfg.human_policy != MCN_HUMANS_ORCA || p.force_generic || !p.update || p.N < 6 || p.N > 10) return false;
+    if (p.lp3_defer > 0 || p.step_block == 256) return false;          // forced other decompositions
+    const int G = 64 / p.N;
+    const int waves_total = (p.E + G - 1) / G;
+    const int nc = p.N - 1 + (p.cfg.robot_visible ? 1 : 0);
+    if (p.step_block != 64 && waves_total > (nc >= 8 ? 12288 : 4096)) return false;   // launch_env_step's own rule
+    StepParams q = p;
+    q.lp3_defer = 0;
+    q.G = G;
+    const size_t sm = step_smem_bytes(64, p.N / 2, nc >= 5);
+#define MCN_LOOP_CASE(NT_) case NT_: \
+        if (p.cfg.robot_visible) hipLaunchKernelGGL((env_step_loop_kernel<NT_, 1>), dim3(waves_total), dim3(64), sm, stream, q, T); \
+        else                     hipLaunchKernelGGL((env_step_loop_kernel<NT_, 0>), dim3(waves_total), dim3(64), sm, stream, q, T); \
+        return true;
+    switch (p.N) {
+        MCN_LOOP_CASE(6) MCN_LOOP_CASE(7) MCN_LOOP_CASE(8) MCN_LOOP_CASE(9) MCN_LOOP_CASE(10)
+        default: break;
+    }
+#undef MCN_LOOP_CASE
+    return false;
 }
 
 bool launch_env_step_quad(const StepParams &p, hipStream_t stream);      // env_step_quad.hip

@@ -12,6 +12,7 @@
 namespace mcn {
 int launch_env_step(const StepParams &p, hipStream_t stream);
 bool launch_env_rollout_quad(const StepParams &p, int T, hipStream_t stream);
+bool launch_env_step_loop(const StepParams &p, int T, hipStream_t stream);
 int launch_scenario_pool(const mcn_scenario_cfg &c, uint64_t seed, int64_t first_case, int P, int N, double *hpos,
                          double *hgoal, double *hrad, double *hvpref, hipStream_t stream);
 struct SarlParams;
@@ -189,6 +190,10 @@ int mcn_env_rollout(const mcn_env_cfg *cfg, const mcn_env_state *st, const doubl
     if (fused && !p.force_generic && mcn::launch_env_rollout_quad(p, T, (hipStream_t)stream))
         return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
     p.quad_split = step_split;
+    // 6-10 ORCA humans, latency-bound batch: the one-wavefront step kernel run T times inside one launch
+    // (env_step.hip: env_step_loop_kernel); rollout_fused = 0 keeps the T launches
+    if (tu.rollout_fused != 0 && T > 1 && mcn::launch_env_step_loop(p, T, (hipStream_t)stream))
+        return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
     for (int32_t t = 0; t < T; ++t) {
         p.actions = actions + (size_t)t * E * 2;
         const int r = mcn::launch_env_step(p, (hipStream_t)stream);

@@ -301,10 +301,11 @@ def test_rollout_launch_equals_single_steps(N, visible, with_pool, split, tuning
 @pytest.mark.parametrize("N,visible", [(10, False), (7, True), (6, False)])
 @pytest.mark.parametrize("defer", [0, 1])
 def test_rollout_entry_point_with_larger_crowds(N, visible, defer, tuning):
-    """mcn_env_rollout for crowds the fused launch does not cover (more than 4 ORCA neighbours per human): the entry
-    point runs its T single-step launches (the wavefront-cooperative 3-D LP of one-wavefront workgroups included) and
-    must leave every byte as T mcn_env_step calls do (the oracle comparison of these kernels over whole trajectories
-    is test_larger_crowd_trajectories_match_oracle)."""
+    """mcn_env_rollout for crowds the quad-parallel rollout kernel does not cover (more than 4 ORCA neighbours per
+    human): defer = 0 takes env_step_loop_kernel -- the one-wavefront step kernel (cooperative 3-D LP included) run T
+    times inside ONE launch --, defer = 1 the T single-step launches with parked 3-D LPs; both must leave every byte as T
+    mcn_env_step calls do (the oracle comparison over whole trajectories is test_larger_crowd_trajectories_match_oracle
+    and, for the looped launch, test_looped_rollout_launch_matches_oracle_trajectory)."""
     torch = _torch()
     E, T = 300, 110
     rng = np.random.RandomState(N)
@@ -325,6 +326,31 @@ def test_rollout_entry_point_with_larger_crowds(N, visible, defer, tuning):
     for k in sa:
         assert np.array_equal(sa[k].view(np.uint8), sb[k].view(np.uint8)), k
     assert int(a.rollout_buffers["fin_count"].min().item()) >= 1
+
+
+@pytest.mark.parametrize("N,visible", [(10, False), (7, True), (9, False), (8, True), (6, False)])
+def test_looped_rollout_launch_matches_oracle_trajectory(N, visible, tuning):
+    """env_step_loop_kernel (mcn_env_rollout for 6-10 ORCA humans in a latency-bound batch: T steps in ONE launch, the
+    state going through L2 between iterations) against the oracle stepping the same 60-step action sequence: the state
+    after the launch, bit for bit -- and the same launch with rollout_fused = 0 (T step launches) for the record."""
+    torch = _torch()
+    E, T = 700, 60
+    rng = np.random.RandomState(100 + N)
+    sp, aa = rng.uniform(0, 1, (T, E)), rng.uniform(0, 2 * np.pi, (T, E))
+    ax, ay = sp * np.cos(aa), sp * np.sin(aa)
+    env = H.make_vec_env(E, N, robot_visible=visible)
+    env.reset("test", test_cases=[i % 500 for i in range(E)])
+    st = H.download(env)
+    cfg = H.oracle_cfg_for(env)
+    cport.lp3_entries(reset=True)
+    tuning(lp3_defer=0)
+    env.rollout(torch.from_numpy(np.stack([ax, ay], -1)).to(env.device))
+    for t in range(T):
+        ref = cport.env_step(cfg, st, ax[t], ay[t], update=True)
+    H.assert_state_equal(H.download(env), st, what="after one %d-step launch" % T)
+    assert np.array_equal(env.reward.cpu().numpy(), ref["reward"]) and np.array_equal(env.done.cpu().numpy(), ref["done"])
+    assert np.array_equal(env.human_act.cpu().numpy(), ref["human_act"])          # outputs of the last step
+    assert cport.lp3_entries() > 100, "the crossing should drive humans into the 3-D LP"
 
 
 @pytest.mark.parametrize("N", [7, 10, 5])

@@ -10,7 +10,7 @@ gfx950 reports half of the bytes of wide coalesced loads, so reads are doubled; 
 kernels are kept; launches are grouped by (kernel name, grid size) and averaged.
 
 Every entry says which kernel FAMILY it is (env_pair_kernel / env_step_kernel / env_step_quad_kernel /
-env_rollout_quad_kernel / sarl_value_kernel / sgan_*_kernel), which human-policy MODE that instantiation computes
+env_rollout_quad_kernel / env_step_loop_kernel / sarl_value_kernel / sgan_*_kernel), which human-policy MODE that instantiation computes
 (parsed from the template arguments, never guessed from a substring) and on how many envs of how many humans it ran
 (the run's batch size whose lane count matches the launch's grid); bench.py matches on exactly those.
 """
@@ -68,7 +68,7 @@ def summarise(run, algorithmic):
             E = match_envs(grid, n, lph, sizes)
         if E is None:
             continue
-        S = spl if fam == "env_rollout_quad_kernel" else 1
+        S = spl if fam in ("env_rollout_quad_kernel", "env_step_loop_kernel") else 1
         rd, wr = 2.0 * fetch[key] * 1024.0, write[key] * 1024.0
         e = {"kernel": name, "family": fam, "mode": mode, "humans": n, "envs": E, "steps_per_launch": S,
              "grid_threads": grid, "workgroup": wg, "launches_averaged": n_f[key],

@@ -33,6 +33,7 @@ pmc o5  --sizes 4096,65536,1048576 --modes orca --iters 20
 pmc g5  --sizes 4096,1048576 --modes given --no-hh --iters 20
 pmc o10 --humans 10 --sizes 4096,262144 --modes orca --iters 20
 for T in 20 100 1000; do pmc r$T --rollout $T --sizes 4096; done
+for T in 50 200; do pmc r10_$T --rollout $T --humans 10 --sizes 4096; done      # env_step_loop_kernel<10, 0>
 pmc sarl5  --sarl --humans 5
 pmc sarl10 --sarl --humans 10
 pmc sgan10 --sgan --humans 10 --sizes 4096 --iters 20
@@ -47,6 +48,7 @@ sq roll  --rollout 200 --sizes 4096
 sq step  --sizes 4096,1048576 --modes orca --iters 20
 sq given --sizes 1048576 --modes given --no-hh --iters 20
 sq o10   --humans 10 --sizes 4096,262144 --modes orca --iters 20
+sq roll10 --rollout 200 --humans 10 --sizes 4096
 echo "pmc SQ done"
 cd "$ROOT"
 R() { echo "$OUT/$1_FETCH_SIZE:$OUT/$1_WRITE_SIZE:$2:$3:$4"; }
@@ -54,11 +56,11 @@ python3 tools/pmc_summary.py "$DST/${TAG}_pmc_env_step.json" --run "$(R o5 5 409
     --run "$(R g5 5 4096+1048576 1)" --run "$(R o10 10 4096+262144 1)" \
     --note "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (counter unit KB, FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as is); one kbench run per workload: ORCA humans x 5, given velocities x 5 (ModelCrowdSim.step: no human-human count), ORCA humans x 10."
 python3 tools/pmc_summary.py "$DST/${TAG}_pmc_env_rollout.json" --run "$(R r20 5 4096 20)" --run "$(R r100 5 4096 100)" \
-    --run "$(R r1000 5 4096 1000)"
+    --run "$(R r1000 5 4096 1000)" --run "$(R r10_50 10 4096 50)" --run "$(R r10_200 10 4096 200)"
 python3 tools/pmc_summary.py "$DST/${TAG}_pmc_nets.json" --run "$(R sarl5 5 4096 1)" --run "$(R sarl10 10 4096 1)" \
     --run "$(R sgan10 10 4096 1)" --only sarl_,sgan_
-python3 tools/pmc_sq_summary.py "$OUT/sq_roll,$OUT/sq_step,$OUT/sq_given,$OUT/sq_o10" "$DST/${TAG}_pmc_sq.json" \
-    --spec "env_rollout_quad_kernel<5=rollout:4096:5:200;env_step_quad_kernel<5=quad:4096:5:1;env_step_kernel<256, 5, 0, 0=fused:1048576:5:1;env_pair_kernel<5=pairwise:1048576:5:1;env_step_kernel<64, 10, 0, 0=fused:4096:10:1;env_step_kernel<256, 10, 0, 0=fused:262144:10:1"
+python3 tools/pmc_sq_summary.py "$OUT/sq_roll,$OUT/sq_step,$OUT/sq_given,$OUT/sq_o10,$OUT/sq_roll10" "$DST/${TAG}_pmc_sq.json" \
+    --spec "env_step_loop_kernel<10=loop:4096:10:200;env_rollout_quad_kernel<5=rollout:4096:5:200;env_step_quad_kernel<5=quad:4096:5:1;env_step_kernel<256, 5, 0, 0=fused:1048576:5:1;env_pair_kernel<5=pairwise:1048576:5:1;env_step_kernel<64, 10, 0, 0=fused:4096:10:1;env_step_kernel<256, 10, 0, 0=fused:262144:10:1"
 # 1c. matrix-pipe counters of the network kernels (SARL look-ahead, SGAN step): one pass each
 MF="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 cd /tmp

@@ -164,8 +164,9 @@ int mcn_env_step(const mcn_env_cfg *cfg, const mcn_env_state *st, const double *
  * mcn_env_rollout -- T consecutive mcn_env_step(update = 1) calls with the action sequence actions[T][E][2],
  * same results bit for bit.  Replaces the step loop of Explorer.run_k_episodes (crowd_nav/utils/explorer.py:69-99)
  * for robots whose actions do not depend on the observation (random / scripted sequences).  Where the batch is
- * small enough to be latency-bound and every human has <= 4 ORCA neighbours, the T steps run in ONE launch with
- * the env state held in registers; otherwise this is T launches.  On return `st` is the state after step T,
+ * small enough to be latency-bound the T steps run in ONE launch: with <= 4 ORCA neighbours per human the env state
+ * stays in registers (env_rollout_quad.hip), with 6-10 ORCA humans the one-wavefront step kernel runs T times and the
+ * state goes through L2 (env_step.hip: env_step_loop_kernel); otherwise this is T launches.  On return `st` is the state after step T,
  * `out->rec` / `out->human_act` are those of step T, `roll` has accounted for all T steps (episodes that end
  * inside the sequence are recorded and, with a pool, restarted in-kernel).  Humans: ORCA or linear (no given_v).
  */

@@ -631,11 +631,13 @@ static void dispatch(const StepParams &p, int blocks, hipStream_t stream)
     }
 }
 
-// mcn_env_rollout for 6-10 ORCA humans in a latency-bound batch: one env_step_loop_kernel launch instead of T step
+// mcn_env_rollout for 6-10 ORCA humans (and 5 with a visible robot) in a latency-bound batch: one env_step_loop_kernel launch instead of T step
 // launches.  false = not applicable (the caller falls back to T launches).
 bool launch_env_step_loop(const StepParams &p, int T, hipStream_t stream)
 {
-    if (p.cfg.human_policy != MCN_HUMANS_ORCA || p.force_generic || !p.update || p.N < 6 || p.N > 10) return false;
+    // (5 humans + a visible robot = 5 neighbours: one more than the quad-parallel rollout kernel takes)
+    const bool five_vis = p.N == 5 && p.cfg.robot_visible;
+    if (p.cfg.human_policy != MCN_HUMANS_ORCA || p.force_generic || !p.update || ((p.N < 6 || p.N > 10) && !five_vis)) return false;
     if (p.lp3_defer > 0 || p.step_block == 256) return false;          // forced other decompositions
     const int G = 64 / p.N;
     const int waves_total = (p.E + G - 1) / G;
@@ -650,6 +652,7 @@ bool launch_env_step_loop(const StepParams &p, int T, hipStream_t stream)
         else                     hipLaunchKernelGGL((env_step_loop_kernel<NT_, 0>), dim3(waves_total), dim3(64), sm, stream, q, T); \
         return true;
     switch (p.N) {
+        case 5: hipLaunchKernelGGL((env_step_loop_kernel<5, 1>), dim3(waves_total), dim3(64), sm, stream, q, T); return true;
         MCN_LOOP_CASE(6) MCN_LOOP_CASE(7) MCN_LOOP_CASE(8) MCN_LOOP_CASE(9) MCN_LOOP_CASE(10)
         default: break;
     }

@@ -298,7 +298,7 @@ def test_rollout_launch_equals_single_steps(N, visible, with_pool, split, tuning
         assert np.array_equal(sc[k].view(np.uint8), sb[k].view(np.uint8)), k
 
 
-@pytest.mark.parametrize("N,visible", [(10, False), (7, True), (6, False)])
+@pytest.mark.parametrize("N,visible", [(10, False), (7, True), (6, False), (5, True)])
 @pytest.mark.parametrize("defer", [0, 1])
 def test_rollout_entry_point_with_larger_crowds(N, visible, defer, tuning):
     """mcn_env_rollout for crowds the quad-parallel rollout kernel does not cover (more than 4 ORCA neighbours per
@@ -328,7 +328,7 @@ def test_rollout_entry_point_with_larger_crowds(N, visible, defer, tuning):
     assert int(a.rollout_buffers["fin_count"].min().item()) >= 1
 
 
-@pytest.mark.parametrize("N,visible", [(10, False), (7, True), (9, False), (8, True), (6, False)])
+@pytest.mark.parametrize("N,visible", [(10, False), (7, True), (9, False), (8, True), (6, False), (5, True)])
 def test_looped_rollout_launch_matches_oracle_trajectory(N, visible, tuning):
     """env_step_loop_kernel (mcn_env_rollout for 6-10 ORCA humans in a latency-bound batch: T steps in ONE launch, the
     state going through L2 between iterations) against the oracle stepping the same 60-step action sequence: the state

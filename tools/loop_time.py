@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""GPU box: per-step time of mcn_env_rollout for 6-10 ORCA humans -- one looped launch (env_step_loop_kernel) against
+the T single-step launches `mcn_tuning.rollout_fused = 0` keeps.  python tools/loop_time.py"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch

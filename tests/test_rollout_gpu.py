@@ -87,11 +87,13 @@ def test_vec_explorer_case_counter_wraps_mid_run():
     assert got["danger_steps"] == sum(w[3] for w in want)
 
 
-def test_vec_explorer_action_sequence_uses_fused_rollout():
-    """A pre-drawn action sequence run through mcn_env_rollout chunks gives the records of the per-step loop."""
+@pytest.mark.parametrize("N", [5, 10])
+def test_vec_explorer_action_sequence_uses_fused_rollout(N):
+    """A pre-drawn action sequence run through mcn_env_rollout chunks gives the records of the per-step loop: 5 humans
+    through the quad-parallel rollout kernel, 10 through the looped step kernel (env_step_loop_kernel)."""
     import torch
     from modelcrowdnav_amd.rollout import VecExplorer
-    E, N, k, T = 48, 5, 100, 330
+    E, k, T = 48, 100, 330
     rng = np.random.RandomState(5)
     sp, aa = rng.uniform(0, 1, (T, E)), rng.uniform(0, 2 * np.pi, (T, E))
     recs = []

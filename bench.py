@@ -412,10 +412,12 @@ def extra_configs(device):
             a, _ = pol4.predict_batch(env)
             env.step(a)                      # picks the prefetched velocities up
         ms4 = _timed(step4, 20)
+        ms_sarl10 = _timed(lambda: pol4.predict_batch(env), 20)         # the look-ahead alone: what bounds this step
         ms_sgan = _timed(lambda: world(env.hpos), 96)           # three host noise blocks (VecSGANWorld.draw_noise)
         out.append({"config": "4096 envs x 10 humans, model-based rollout: SGAN (pool-net, zara1_8) world model + SARL robot",
                     "ms_per_step": round(ms4, 4), "env_steps_per_sec": round(E / ms4 * 1e3, 1),
-                    "sgan_step_ms": round(ms_sgan, 4),
+                    "sgan_step_ms": round(ms_sgan, 4), "sarl_lookahead_ms": round(ms_sarl10, 4),
+                    "roofline_sarl": _sarl_roofline(E, N, ms_sarl10),
                     # ~0.69 MFLOP per pedestrian for the pooling generator at N = 10 as the reference
                     # writes it (8 encoder LSTM steps, N pool-net MLPs 48 -> 512 -> 8 per pedestrian, context MLP,
                     # decoder LSTM step): `achieved` / `frac` follow that definition.  The kernels execute fewer: the

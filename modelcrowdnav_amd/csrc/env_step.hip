@@ -631,6 +631,14 @@ static void dispatch(const StepParams &p, int blocks, hipStream_t stream)
     }
 }
 
+// Small batches run one wavefront per workgroup so that the grid covers as many CUs as possible (crowds of 9-10: the
+// one-wavefront workgroups with the cooperative 3-D LP stay ahead longer -- 10 humans, 32 768 envs 63.6 vs 67.1 us,
+// 65 536 envs 105 vs 110, 2^18 envs 391 vs 307; 7 humans cross at ~24 k envs).  mcn_tuning.step_block overrides.
+static bool one_wave_batch(const StepParams &p, int waves_total, int nc)
+{
+    return p.step_block > 0 ? p.step_block == 64 : waves_total <= (nc >= 8 ? 12288 : 4096);
+}
+
 // mcn_env_rollout for 6-10 ORCA humans (and 5 with a visible robot) in a latency-bound batch: one env_step_loop_kernel launch instead of T step
 // launches.  false = not applicable (the caller falls back to T launches).
 bool launch_env_step_loop(const StepParams &p, int T, hipStream_t stream)
@@ -638,11 +646,11 @@ bool launch_env_step_loop(const StepParams &p, int T, hipStream_t stream)
     // (5 humans + a visible robot = 5 neighbours: one more than the quad-parallel rollout kernel takes)
     const bool five_vis = p.N == 5 && p.cfg.robot_visible;
     if (p.cfg.human_policy != MCN_HUMANS_ORCA || p.force_generic || !p.update || ((p.N < 6 || p.N > 10) && !five_vis)) return false;
-    if (p.lp3_defer > 0 || p.step_block == 256) return false;          // forced other decompositions
+    if (p.lp3_defer > 0) return false;                                 // forced deferral: two kernels per step
     const int G = 64 / p.N;
     const int waves_total = (p.E + G - 1) / G;
     const int nc = p.N - 1 + (p.cfg.robot_visible ? 1 : 0);
-    if (p.step_block != 64 && waves_total > (nc >= 8 ? 12288 : 4096)) return false;   // launch_env_step's own rule
+    if (!one_wave_batch(p, waves_total, nc)) return false;             // launch_env_step's own rule
     StepParams q = p;
     q.lp3_defer = 0;
     q.G = G;
@@ -685,11 +693,7 @@ int launch_env_step(const StepParams &p_in, hipStream_t stream)
     // given velocities, large batch: the streaming form (env_pair.hip); mcn_tuning.pair_stream overrides
     if ((p.pair_stream > 0 || (p.pair_stream < 0 && waves_total > 4096)) && launch_env_pair(p, stream))
         return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;
-    // small batches: one wavefront per workgroup so the grid covers as many CUs as possible
-    // (crowds of 9-10: the one-wavefront workgroups with the cooperative 3-D LP stay ahead longer -- 10 humans,
-    //  32 768 envs 63.6 vs 67.1 us, 65 536 envs 105 vs 110, 2^18 envs 391 vs 307; 7 humans cross at ~24 k envs)
-    const bool one_wave = p.step_block > 0 ? p.step_block == 64 : waves_total <= (nc >= 8 ? 12288 : 4096);
-    if (one_wave) dispatch<64>(p, waves_total, stream);
+    if (one_wave_batch(p, waves_total, nc)) dispatch<64>(p, waves_total, stream);
     else                     dispatch<256>(p, (waves_total + 3) / 4, stream);
     if (p.lp3_defer) launch_env_lp3(p, stream);
     return hipGetLastError() == hipSuccess ? MCN_OK : MCN_ELAUNCH;

@@ -493,18 +493,24 @@ class CrowdSim(object):
         robot.set()/human.set()): re-upload the few scalars before launching."""
         v, r = self._vec, self._vec.robot
         hs = self.humans
-        dev, f64 = v.device, torch.float64
-        t = lambda rows: torch.tensor(rows, dtype=f64, device=dev)
-        v.hpos.copy_(t([[h.px, h.py] for h in hs]).view(1, -1, 2))
-        v.hvel.copy_(t([[h.vx, h.vy] for h in hs]).view(1, -1, 2))
-        v.hgoal.copy_(t([[h.gx, h.gy] for h in hs]).view(1, -1, 2))
-        v.hrad.copy_(t([h.radius for h in hs]).view(1, -1))
-        v.hvpref.copy_(t([h.v_pref for h in hs]).view(1, -1))
-        v.rpos.copy_(t([[r.px, r.py]])); v.rvel.copy_(t([[r.vx, r.vy]]))
-        v.rgoal.copy_(t([[r.gx, r.gy]])); v.rrad.copy_(t([r.radius])); v.rvpref.copy_(t([r.v_pref]))
-        v.rtheta.copy_(t([r.theta])); v.gtime.copy_(t([self.global_time]))
-        if len(self.human_times) == len(hs):
-            v.human_times.copy_(t([self.human_times]))
+        n = len(hs)
+        # one host row -> one host-to-device copy -> one multi-tensor device copy into the state arrays
+        row = [c for h in hs for c in (h.px, h.py)] + [c for h in hs for c in (h.vx, h.vy)] + \
+              [c for h in hs for c in (h.gx, h.gy)] + [h.radius for h in hs] + [h.v_pref for h in hs] + \
+              [r.px, r.py, r.vx, r.vy, r.gx, r.gy, r.radius, r.v_pref, r.theta, self.global_time]
+        dsts = [v.hpos, v.hvel, v.hgoal, v.hrad, v.hvpref, v.rpos, v.rvel, v.rgoal, v.rrad, v.rvpref, v.rtheta, v.gtime]
+        sizes = [2 * n, 2 * n, 2 * n, n, n, 2, 2, 2, 1, 1, 1, 1]
+        if len(self.human_times) == n:
+            row += list(self.human_times)
+            dsts.append(v.human_times)
+            sizes.append(n)
+        stage = torch.tensor(row, dtype=torch.float64).to(v.device)
+        srcs = [piece.view(d.shape) for piece, d in zip(torch.split(stage, sizes), dsts)]
+        if hasattr(torch, "_foreach_copy_"):
+            torch._foreach_copy_(dsts, srcs)
+        else:
+            for d, piece in zip(dsts, srcs):
+                d.copy_(piece)
 
     def _action_tensor(self, action):
         return torch.tensor([[action[0], action[1]]], dtype=torch.float64, device=self._vec.device)
@@ -535,24 +541,30 @@ class CrowdSim(object):
         v.track_human_times = track
         v.export_human_actions = True
         ob, reward, done, info = self._vec_step(self._action_tensor(action), update)
-        pos, vel = ob.pos[0].cpu().tolist(), ob.vel[0].cpu().tolist()
-        reward, done, code = float(reward.item()), bool(done.item()), int(info.item())
-        info_obj = I.from_code(code, float(v.dmin.item()))
+        # everything the host mirrors need, gathered on the device and fetched with ONE synchronising copy
+        n = len(self.humans)
+        host = torch.cat([ob.pos[0].reshape(-1), ob.vel[0].reshape(-1), v.step_rec[0], v.rpos[0], v.rvel[0],
+                          v.rtheta, v.gtime, v.human_times[0]]).cpu().numpy()
+        pos, vel = host[:2 * n].reshape(n, 2).tolist(), host[2 * n:4 * n].reshape(n, 2).tolist()
+        rec = host[4 * n:4 * n + 3]
+        flags = rec[2:3].view(np.uint8)                              # mcn_step_rec: done, info at bytes 16, 17
+        reward, done, code = float(rec[0]), bool(flags[0]), int(flags[1])
+        info_obj = I.from_code(code, float(rec[1]))
+        tail = host[4 * n + 3:]                                      # rpos 2, rvel 2, rtheta, gtime, human_times n
         if update:
             self.states.append([robot.get_full_state(), [h.get_full_state() for h in self.humans]])
             if hasattr(robot.policy, "action_values"):
                 self.action_values.append(robot.policy.action_values)
             if hasattr(robot.policy, "get_attention_weights"):
                 self.attention_weights.append(robot.policy.get_attention_weights())
-            rp, rv = v.rpos[0].cpu().tolist(), v.rvel[0].cpu().tolist()
-            robot.px, robot.py, robot.vx, robot.vy = rp[0], rp[1], rv[0], rv[1]
+            robot.px, robot.py, robot.vx, robot.vy = float(tail[0]), float(tail[1]), float(tail[2]), float(tail[3])
             if robot.kinematics == "unicycle":
-                robot.theta = float(v.rtheta.item())
+                robot.theta = float(tail[4])
             for h, p, w in zip(self.humans, pos, vel):
                 h.px, h.py, h.vx, h.vy = p[0], p[1], w[0], w[1]
-            self.global_time = float(v.gtime.item())
+            self.global_time = float(tail[5])
             if track:
-                self.human_times = v.human_times[0].cpu().tolist()
+                self.human_times = tail[6:6 + n].tolist()
             out = [h.get_observable_state() for h in self.humans]
         else:
             out = [ObservableState(p[0], p[1], w[0], w[1], h.radius) for h, p, w in zip(self.humans, pos, vel)]

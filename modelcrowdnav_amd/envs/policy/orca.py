@@ -47,10 +47,14 @@ class ORCA(Policy):
         for k, o in enumerate(others):
             oth[k] = np.array([o.px, o.py, o.vx, o.vy, o.radius + 0.01 + self.safety_space],
                               dtype=np.float64).astype(np.float32)
-        d_self = torch.from_numpy(self_row).to(dev)
-        d_oth = torch.from_numpy(oth).to(dev)
-        d_n = torch.tensor([m], dtype=torch.int32, device=dev)
-        d_out = torch.empty(2, dtype=torch.float32, device=dev)
+        # one host buffer, one copy: [self 8 | others 5 M | count (int32 bits) | 2 output slots]
+        M = max(m, 1)
+        host = np.zeros(8 + 5 * M + 3, np.float32)
+        host[:8], host[8:8 + 5 * M] = self_row, oth.reshape(-1)
+        host[8 + 5 * M:9 + 5 * M].view(np.int32)[0] = m
+        stage = torch.from_numpy(host).to(dev)
+        d_self, d_oth = stage[:8], stage[8:8 + 5 * M]
+        d_n, d_out = stage[8 + 5 * M:9 + 5 * M].view(torch.int32), stage[9 + 5 * M:]
         _hip.check(_hip.lib.mcn_orca_batch(_hip.ptr(d_self), _hip.ptr(d_oth), _hip.ptr(d_n), _hip.ptr(d_out),
                                            1, max(m, 1), float(self.neighbor_dist), int(self.max_neighbors),
                                            float(self.time_horizon), float(self.time_step), _hip.stream_ptr(dev)),

@@ -128,12 +128,14 @@ class MultiHumanRL(CADRL):
         else:
             dev = self._gpu_device()
             N = len(humans)
-            f64 = torch.float64
-            t = lambda rows: torch.tensor(rows, dtype=f64, device=dev)
-            bufs = dict(hpos=t([[h.px, h.py] for h in humans]), hvel=t([[h.vx, h.vy] for h in humans]),
-                        hrad=t([h.radius for h in humans]), rpos=t([[me.px, me.py]]),
-                        rvel=t([[me.vx, me.vy]]), rgoal=t([[me.gx, me.gy]]), rrad=t([me.radius]), rvpref=t([me.v_pref]),
-                        rtheta=t([me.theta]))
+            # one host row, one host-to-device copy; the state arrays are views of it (16-byte aligned: pairs first)
+            row = [c for h in humans for c in (h.px, h.py)] + [c for h in humans for c in (h.vx, h.vy)] + \
+                  [me.px, me.py, me.vx, me.vy, me.gx, me.gy] + [h.radius for h in humans] + [me.radius, me.v_pref, me.theta]
+            stage = torch.tensor(row, dtype=torch.float64).to(dev)
+            names = ("hpos", "hvel", "rpos", "rvel", "rgoal", "hrad", "rrad", "rvpref", "rtheta")
+            sizes = (2 * N, 2 * N, 2, 2, 2, N, 1, 1, 1)
+            shapes = ((N, 2), (N, 2), (1, 2), (1, 2), (1, 2), (N,), (1,), (1,), (1,))
+            bufs = {k: piece.view(shp) for k, piece, shp in zip(names, torch.split(stage, sizes), shapes)}
             st = _hip.EnvState()
             for k, v in bufs.items():
                 setattr(st, k, _hip.ptr(v))

@@ -592,7 +592,6 @@ def g14_model_env():
         rec["scs_rob_%d" % c], rec["scs_hum_%d" % c] = G.full_state_rows(env)
         rec["scs_global_time_%d" % c] = np.array(env.global_time, np.float64)
     # ---- episodes: humans moved by an MlpWorld module (the non-SGAN branch of :398-407), robot actions from the table
-    table = _sarl_policy(0).__class__          # noqa: F841  (imports the policy package once)
     pol0 = _sarl_policy(0)
     pol0.kinematics = "holonomic"
     pol0.build_action_space(1.0)

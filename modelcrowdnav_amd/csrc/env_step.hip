@@ -651,6 +651,10 @@ bool launch_env_step_loop(const StepParams &p, int T, hipStream_t stream)
     const int waves_total = (p.E + G - 1) / G;
     const int nc = p.N - 1 + (p.cfg.robot_visible ? 1 : 0);
     if (!one_wave_batch(p, waves_total, nc)) return false;             // launch_env_step's own rule
+    // The looped kernel holds 234-282 VGPRs (one wavefront per SIMD) against the step kernel's 160 (three): it wins while
+    // the batch leaves SIMDs idle anyway and loses once wavefronts queue up -- 10 humans: 4096 envs 28.9 -> 14.9 us per
+    // step, 16 384 envs (2731 wavefronts) 43.0 -> 41.3, 32 768 envs (5462) 64.2 -> 80.7.
+    if (p.step_block != 64 && waves_total > 3072) return false;
     StepParams q = p;
     q.lp3_defer = 0;
     q.G = G;

@@ -40,7 +40,8 @@ def test_kernel_classification_reads_template_arguments():
     # while the batch is latency-bound (launch_env_step_loop), T step launches beyond
     assert c("mcn::env_step_loop_kernel<10, 0>") == ("env_step_loop_kernel", 10, "orca", 1)
     assert e(4096, 5, False, 1000) == "env_rollout_quad_kernel"
-    assert e(4096, 10, False, 500) == "env_step_loop_kernel" and e(32768, 10, False, 500) == "env_step_loop_kernel"
+    assert e(4096, 10, False, 500) == "env_step_loop_kernel" and e(16384, 10, False, 500) == "env_step_loop_kernel"
+    assert e(32768, 10, False, 500) == "env_step_kernel"          # 5462 wavefronts: throughput-bound, T launches
     assert e(4096, 7, False, 100) == "env_step_loop_kernel" and e(65536, 7, False, 100) == "env_step_kernel"
     assert e(1 << 18, 10, False, 100) == "env_step_kernel"
     assert e(4096, 10, False) == "env_step_kernel" and e(4096, 5, False, 20) == "env_rollout_quad_kernel"

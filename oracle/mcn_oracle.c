@@ -151,15 +151,17 @@ static void lp3(const hline *L, int n, int begin, float radius, v2 *res)
 }
 
 /*
- * One agent's ORCA velocity.  `o*` arrays describe the candidate neighbours in
- * insertion order (index order, self skipped, robot last when visible --
- * crowd_sim.py:339-341, orca.py:99-110).
+ * Neighbour selection + half-plane construction of one agent (RVO2 Agent::computeNeighbors /
+ * computeNewVelocity up to the linear programs; call sites orca.py:95-129).  ONE function: the solver
+ * (mcn_oracle_orca_agent) and the test hook (mcn_oracle_orca_lines) both call it, so the independent geometry pins of
+ * tests/test_orca_pins.py exercise exactly the lines the solver optimises over.
+ * `o*` arrays describe the candidate neighbours in insertion order (index order, self skipped, robot last when
+ * visible -- crowd_sim.py:339-341, orca.py:99-110).  Returns the number of lines written to L (solver order).
  */
-void mcn_oracle_orca_agent(float px, float py, float vx, float vy, float radius, float max_speed,
-                           float pref_x, float pref_y, int n_other,
-                           const float *opx, const float *opy, const float *ovx, const float *ovy,
-                           const float *orad, float neighbor_dist, int max_neighbors,
-                           float time_horizon, float time_step, float *out_vx, float *out_vy)
+static int orca_build_lines(v2 pos, v2 vel, float radius, int n_other,
+                            const float *opx, const float *opy, const float *ovx, const float *ovy,
+                            const float *orad, float neighbor_dist, int max_neighbors,
+                            float time_horizon, float time_step, hline *L)
 {
     /* neighbour selection: stable insertion by squared distance, shrinking range
        once the list is full (RVO2 Agent::insertAgentNeighbor). */
@@ -167,7 +169,6 @@ void mcn_oracle_orca_agent(float px, float py, float vx, float vy, float radius,
     float dsq[MCN_MAX_NEIGH];
     int   cnt = 0;
     float range_sq = sqrf(neighbor_dist);
-    const v2 pos = V(px, py), vel = V(vx, vy);
     if (max_neighbors > MCN_MAX_NEIGH) max_neighbors = MCN_MAX_NEIGH;
     if (max_neighbors > 0) {
         for (int j = 0; j < n_other; ++j) {
@@ -182,7 +183,6 @@ void mcn_oracle_orca_agent(float px, float py, float vx, float vy, float radius,
         }
     }
 
-    hline L[MCN_MAX_NEIGH];
     const float inv_th = 1.0f / time_horizon;
     for (int k = 0; k < cnt; ++k) {
         const int j = idx[k];
@@ -223,62 +223,38 @@ void mcn_oracle_orca_agent(float px, float py, float vx, float vy, float radius,
         ln.p = vadd(vel, vscale(0.5f, u));
         L[k] = ln;
     }
+    return cnt;
+}
 
+/* One agent's ORCA velocity: the half-planes above, then the incremental 2-D LP and, if it fails, the 3-D LP. */
+void mcn_oracle_orca_agent(float px, float py, float vx, float vy, float radius, float max_speed,
+                           float pref_x, float pref_y, int n_other,
+                           const float *opx, const float *opy, const float *ovx, const float *ovy,
+                           const float *orad, float neighbor_dist, int max_neighbors,
+                           float time_horizon, float time_step, float *out_vx, float *out_vy)
+{
+    hline L[MCN_MAX_NEIGH];
+    const int cnt = orca_build_lines(V(px, py), V(vx, vy), radius, n_other, opx, opy, ovx, ovy, orad,
+                                     neighbor_dist, max_neighbors, time_horizon, time_step, L);
     v2 res;
     const int fail = lp2(L, cnt, max_speed, V(pref_x, pref_y), 0, &res);
     if (fail < cnt) lp3(L, cnt, fail, max_speed, &res);
     *out_vx = res.x; *out_vy = res.y;
 }
 
-/* Debug/test hook: the ORCA half-planes of one agent in solver order. */
+/* Debug/test hook: the ORCA half-planes of one agent in solver order -- the SAME lines the solver above sees
+   (one shared construction, orca_build_lines). */
 int mcn_oracle_orca_lines(float px, float py, float vx, float vy, float radius, int n_other,
                           const float *opx, const float *opy, const float *ovx, const float *ovy,
                           const float *orad, float neighbor_dist, int max_neighbors,
                           float time_horizon, float time_step, float *out_lines /* [n][4] */)
 {
-    /* same construction as above, duplicated deliberately so the solver stays one function */
-    int idx[MCN_MAX_NEIGH]; float dsq[MCN_MAX_NEIGH]; int cnt = 0;
-    float range_sq = sqrf(neighbor_dist);
-    const v2 pos = V(px, py), vel = V(vx, vy);
-    if (max_neighbors > MCN_MAX_NEIGH) max_neighbors = MCN_MAX_NEIGH;
-    for (int j = 0; j < n_other && max_neighbors > 0; ++j) {
-        const float d = vabssq(vsub(pos, V(opx[j], opy[j])));
-        if (d < range_sq) {
-            if (cnt < max_neighbors) ++cnt;
-            int i = cnt - 1;
-            while (i != 0 && d < dsq[i - 1]) { dsq[i] = dsq[i - 1]; idx[i] = idx[i - 1]; --i; }
-            dsq[i] = d; idx[i] = j;
-            if (cnt == max_neighbors) range_sq = dsq[cnt - 1];
-        }
-    }
-    const float inv_th = 1.0f / time_horizon;
+    hline L[MCN_MAX_NEIGH];
+    const int cnt = orca_build_lines(V(px, py), V(vx, vy), radius, n_other, opx, opy, ovx, ovy, orad,
+                                     neighbor_dist, max_neighbors, time_horizon, time_step, L);
     for (int k = 0; k < cnt; ++k) {
-        const int j = idx[k];
-        const v2 rp = vsub(V(opx[j], opy[j]), pos);
-        const v2 rv = vsub(vel, V(ovx[j], ovy[j]));
-        const float dist_sq = vabssq(rp), cr = radius + orad[j], cr_sq = sqrf(cr);
-        v2 d, u;
-        if (dist_sq > cr_sq) {
-            const v2 w = vsub(rv, vscale(inv_th, rp));
-            const float wl_sq = vabssq(w), dp1 = vdot(w, rp);
-            if (dp1 < 0.0f && sqrf(dp1) > cr_sq * wl_sq) {
-                const float wl = sqrtf(wl_sq); const v2 uw = vdiv(w, wl);
-                d = V(uw.y, -uw.x); u = vscale(cr * inv_th - wl, uw);
-            } else {
-                const float leg = sqrtf(dist_sq - cr_sq);
-                if (vdet(rp, w) > 0.0f) d = vdiv(V(rp.x * leg - rp.y * cr, rp.x * cr + rp.y * leg), dist_sq);
-                else { const v2 t = vdiv(V(rp.x * leg + rp.y * cr, -rp.x * cr + rp.y * leg), dist_sq); d = V(-t.x, -t.y); }
-                u = vsub(vscale(vdot(rv, d), d), rv);
-            }
-        } else {
-            const float inv_ts = 1.0f / time_step;
-            const v2 w = vsub(rv, vscale(inv_ts, rp));
-            const float wl = sqrtf(vabssq(w)); const v2 uw = vdiv(w, wl);
-            d = V(uw.y, -uw.x); u = vscale(cr * inv_ts - wl, uw);
-        }
-        const v2 p = vadd(vel, vscale(0.5f, u));
-        out_lines[4 * k + 0] = p.x; out_lines[4 * k + 1] = p.y;
-        out_lines[4 * k + 2] = d.x; out_lines[4 * k + 3] = d.y;
+        out_lines[4 * k + 0] = L[k].p.x; out_lines[4 * k + 1] = L[k].p.y;
+        out_lines[4 * k + 2] = L[k].d.x; out_lines[4 * k + 3] = L[k].d.y;
     }
     return cnt;
 }

@@ -512,6 +512,10 @@ def _sgan_roofline(E, N, ms):
             "avg_launch_us": round(ms * 1e3, 1), "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}
 
 
+# the reference's Python CrowdSim.step, `linear` humans, measured once in the build container
+REFERENCE_PYTHON_STEPS_PER_S = 8084.0
+
+
 def cpu_baseline(N, seconds):
     """The C oracle's env step (oracle/mcn_oracle.c) on a bounded sample of the same workload: 4096 envs x 5
     humans from the same scenarios, random table actions.  `value` is ONE thread (the reference is single-threaded);
@@ -551,10 +555,33 @@ def cpu_baseline(N, seconds):
             all_cores = {"value": round(sum(o[0] / o[1] for o in good), 1), "unit": "env-steps/sec", "cores": len(good),
                          "sample": "%d independent replica processes of the same workload, %.1f s each, started "
                                    "together" % (len(good), secs)}
+        # a scalar object-per-agent Python step in the shape of the reference's CrowdSim.step
+        # (tools/py_scalar_step.py: Python objects and loops, one native ORCA solve per human -- the oracle's solver in
+        # place of the absent rvo2), one env at a time in a child process that imports neither torch nor the HIP library
+        python_scalar = None
+        try:
+            psecs = max(2.0, min(10.0, seconds / 2))
+            o = subprocess.run([sys.executable, "-m", "tools.py_scalar_step", path, str(psecs), "16"], cwd=ROOT,
+                               capture_output=True, text=True, timeout=psecs + 60).stdout.split()
+            python_scalar = {"value": round(float(o[0]) / float(o[1]), 1), "unit": "env-steps/sec", "cores": 1,
+                             "kind": "python-scalar",
+                             "sample": "16 envs x %d humans stepped one env at a time for %.1f s, auto-reset; Python "
+                                       "object-per-agent step (the structure of crowd_sim.py:331-434) over the C "
+                                       "oracle's ORCA solve, 1 thread" % (N, float(o[1]))}
+        except Exception as ex:                             # the baseline is a report, never a reason to lose the line
+            python_scalar = {"value": None, "error": repr(ex)}
     return {"value": round(n_env_steps / el, 1), "unit": "env-steps/sec", "cores": 1, "kind": "port",
             "sample": "%d envs x %d humans x %d steps (%.1f s), C oracle, 1 thread; this process may use %d of the "
                       "host's %d cores" % (E, N, steps, el, cores, os.cpu_count()),
-            "all_cores": all_cores}
+            "all_cores": all_cores,
+            "python_scalar": python_scalar,
+            # the real reference cannot travel to the GPU box (and its ORCA needs rvo2, absent everywhere): the figure
+            # SURVEY.md section 6 measured for it in the build container, quoted, not re-measured
+            "reference_python": {"value": REFERENCE_PYTHON_STEPS_PER_S, "unit": "env-steps/sec", "cores": 1,
+                                 "kind": "quoted-constant",
+                                 "sample": "the reference's own CrowdSim.step (crowd_sim.py:331-434), 5 `linear` humans "
+                                           "(no ORCA: rvo2 is absent), zero robot action, 123.7 us per step on 1 of 8 "
+                                           "Xeon 2.1 GHz cores of the build container; source SURVEY.md section 6"}}
 
 
 def main():

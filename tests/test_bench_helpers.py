@@ -149,3 +149,42 @@ def test_pmc_summariser_classifies_by_template_arguments(tmp_path):
     assert by["mcn::env_step_quad_kernel<5, 0, false>"]["envs"] == 4096
     # reads doubled (gfx950 FETCH_SIZE), writes as they are; KB -> bytes; mean of the two launches
     assert pair["traffic_bytes_per_launch"] == int(2 * 1000.5 * 1024 + 500.5 * 1024)
+
+
+def test_python_scalar_baseline_step_equals_the_c_oracle():
+    """bench.py's `cpu_baseline.python_scalar` times tools/py_scalar_step.py (an object-per-agent Python step in the
+    shape of crowd_sim.py:331-434 over the oracle's ORCA solve): before timing it, pin it -- 3 envs x 5 humans x 110
+    steps (collisions, goals, time-outs with auto-reset) against oracle/mcn_oracle.c's batched step, all outputs exact."""
+    import numpy as np
+    from oracle import cport
+    from tools import py_scalar_step as P
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mcn_scen", os.path.join(ROOT, "modelcrowdnav_amd", "envs", "scenarios.py"))
+    S = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(S)
+    pool = S.scenario_pool(S.ScenarioSpec(), "test", range(3), 5, "circle_crossing")
+    st, cfg = cport.EnvState(3, 5), cport.default_cfg()
+    st.hpx[:], st.hpy[:], st.hgx[:], st.hgy[:] = pool[..., 0], pool[..., 1], pool[..., 2], pool[..., 3]
+    st.hr[:], st.hvpref[:] = pool[..., 7], pool[..., 8]
+    st.rpy[:], st.rgy[:], st.rr[:] = -4.0, 4.0, 0.3
+    fresh = st.copy()
+    envs = [P.ScalarCrowdSim(pool[e], cfg) for e in range(3)]
+    rng = np.random.RandomState(3)
+    seen = set()
+    for t in range(110):
+        a = rng.uniform(-1, 1, (3, 2)) * (0.2 if t % 7 else 1.0)
+        a[0] = (0.0, 1.0)                                       # env 0 walks to its goal through the crossing
+        ref = cport.env_step(cfg, st, a[:, 0].copy(), a[:, 1].copy())
+        for e, env in enumerate(envs):
+            ob, reward, done, info, overlaps = env.step(P.ActionXY(a[e, 0], a[e, 1]))
+            assert reward == ref["reward"][e] and bool(done) == bool(ref["done"][e]) and info == ref["info"][e], (t, e)
+            assert overlaps == ref["hh_count"][e]
+            assert [h.px for h in env.humans] == list(st.hpx[e]) and [h.vy for h in env.humans] == list(st.hvy[e])
+            assert (env.robot.px, env.robot.py) == (st.rpx[e], st.rpy[e]) and env.global_time == st.gtime[e]
+            assert env.human_times == list(st.human_times[e])
+            seen.add(int(info))
+            if done:
+                env.reset()
+                for k in cport.EnvState.FIELDS_H + cport.EnvState.FIELDS_R + ("gtime", "human_times"):
+                    getattr(st, k)[e] = getattr(fresh, k)[e]
+    assert {P.TIMEOUT, P.NOTHING} <= seen and len(seen) >= 4, seen

@@ -25,7 +25,8 @@ def average(xs):
     return sum(xs) / len(xs) if xs else 0
 
 
-def value_targets(states, rewards, dones, infos, imitation_learning, gamma_bar, target_model=None, device=None):
+def value_targets(states, rewards, dones, infos, imitation_learning, gamma_bar, target_model=None, device=None,
+                  return_index=False):
     """explorer.py:153-186 (= datagen.py:520-543) for a whole batched rollout.  states [T,E,N,13] f32, rewards
     [T,E] f64, dones [T,E] bool, infos [T,E] u8, gamma_bar = gamma ** (time_step * v_pref).  Returns
     (states [M,N,13], values [M]) of the steps that belong to episodes ending in ReachGoal or Collision (only
@@ -54,6 +55,8 @@ def value_targets(states, rewards, dones, infos, imitation_learning, gamma_bar, 
     idx = keep.t().reshape(-1).nonzero().squeeze(1)           # (env, time) order
     flat_states = states.permute(1, 0, 2, 3).reshape(T * E, states.shape[2], states.shape[3])
     flat_values = values.t().reshape(-1)
+    if return_index:           # positions of the kept rows in the (env, time)-flattened trace: env * T + t
+        return flat_states[idx], flat_values[idx].float(), idx
     return flat_states[idx], flat_values[idx].float()
 
 
@@ -74,7 +77,8 @@ class VecExplorer(object):
 
     def _value_targets(self, states, rewards, dones, infos, imitation_learning):
         gbar = pow(self.gamma, self.env.time_step * float(self.robot.v_pref))
-        return value_targets(states, rewards, dones, infos, imitation_learning, gbar, self.target_model, self.device)
+        return value_targets(states, rewards, dones, infos, imitation_learning, gbar, self.target_model, self.device,
+                             return_index=True)
 
     def _emit_collected(self, cur, ob, rew, done, info, k, rounds, E_total, update_raw_ob, cache_dir):
         """Split the recorded [T,E,...] traces at the dones and hand the k episodes out in the reference's order
@@ -243,9 +247,19 @@ class VecExplorer(object):
             valid = order < rounds
             gidx = (order * E_total + lo + torch.arange(E_local, device=dones.device).unsqueeze(0))
             valid &= gidx < k
-            s, v = self._value_targets(torch.stack(rec_s), torch.stack(rec_r), dones & valid, torch.stack(rec_i),
-                                       imitation_learning)
-            self.memory.push_batch(s, v)
+            s, v, idx = self._value_targets(torch.stack(rec_s), torch.stack(rec_r), dones & valid, torch.stack(rec_i),
+                                            imitation_learning)
+            # the reference pushes episode by episode (explorer.py:107-110): rows go to the memory in global episode
+            # order (episode g = round * E_total + env), time order inside an episode -- a stable sort of the
+            # (env, time)-ordered rows by their episode number
+            ep_of_row = gidx.t().reshape(-1)[idx]
+            perm = torch.argsort(ep_of_row, stable=True)
+            s, v = s[perm], v[perm]
+            if hasattr(self.memory, "push_batch"):
+                self.memory.push_batch(s, v)
+            else:                                                         # any object with the reference's push()
+                for row_s, row_v in zip(s, v):
+                    self.memory.push((row_s, row_v.reshape(1).to(self.device)))
         if collect:
             env.export_human_actions = keep_export
             self._emit_collected(torch.stack(col_cur).cpu().numpy(), torch.stack(col_ob).cpu().numpy(),
@@ -273,8 +287,9 @@ class VecExplorer(object):
         success_times = [tm for tm, c in zip(times, infos) if c == _hip.INFO_REACHGOAL]
         avg_nav_time = sum(success_times) / len(success_times) if success_times else env.time_limit
         extra = "" if episode is None else "in episode {} ".format(episode)
-        logging.info("%-5s %shas success rate: %.2f, collision rate: %.2f, nav time: %.2f, total reward: %.4f",
-                     phase.upper(), extra, success / k, collision / k, avg_nav_time, average(returns))
+        if not stay:                                                       # explorer.py:132
+            logging.info("%-5s %shas success rate: %.2f, collision rate: %.2f, nav time: %.2f, total reward: %.4f",
+                         phase.upper(), extra, success / k, collision / k, avg_nav_time, average(returns))
         if print_failure:
             logging.info("Collision cases: %s", " ".join(str(i) for i, c in enumerate(infos) if c == _hip.INFO_COLLISION))
             logging.info("Timeout cases: %s", " ".join(str(i) for i, c in enumerate(infos) if c == _hip.INFO_TIMEOUT))

@@ -1,7 +1,15 @@
-"""Sequential Explorer with the reference's call surface (crowd_nav/utils/explorer.py:11-192), for drivers
-that run one E = 1 gym env (train.py:120-246, test.py:73-109).  The batched equivalent is
-modelcrowdnav_amd.rollout.VecExplorer; this class exists so `Explorer(env, robot, device, memory, gamma,
+"""Explorer with the reference's call surface (crowd_nav/utils/explorer.py:11-192), for drivers that hold one
+E = 1 gym env (train.py:120-246, test.py:73-109, test_mul_env.py:96-103): `Explorer(env, robot, device, memory, gamma,
 target_policy)` keeps working after `dropin.install()`.
+
+`run_k_episodes(k, ...)` with k > 1 does NOT play the k episodes one after the other on that env: it builds (once) a
+VecCrowdSim of min(k, 4096) environments from the E = 1 env's configuration and robot and hands the call to
+modelcrowdnav_amd.rollout.VecExplorer -- one look-ahead launch and one env launch per step for all episodes side by
+side -- and fills `memory` / `raw_memory` / `rawob` / `cacheFile` in the reference's episode order and returns the
+reference's tuple (pinned by g15_explorer.npz = the reference's own run_k_episodes, tests/test_explorer_golden_gpu.py).
+What stays sequential (`_batched_reason` says why): k = 1 (train.py:218), the train phase of a trainable policy with
+epsilon > 0 (the reference draws exploration from numpy's shared global stream, one draw per step, so the episodes are
+not independent of their order), policies without `predict_batch`, and env classes other than CrowdSim with ORCA humans.
 
 The data-collection side channels are kept (explorer.py:60-85,112-121): `raw_memory` rows `(ob, reward, done, info)`
 for DataGen, `rawob` pairs (humans' [px,py,vx,vy], their next velocities) for the world-model trainers, and the
@@ -39,10 +47,75 @@ class Explorer(object):
     def _discount(self, steps):
         return pow(self.gamma, steps * self.robot.time_step * self.robot.v_pref)
 
+    # largest batch the delegated run builds (tests lower it to force several episodes per env); batched = False keeps
+    # every call on the sequential E = 1 loop
+    max_batch_envs = 4096
+    batched = True
+
+    def _batched_reason(self, k, phase, update_memory, imitation_learning, stay):
+        """None when run_k_episodes can go to the batched VecExplorer, else why not (a short string)."""
+        from ..envs.crowd_sim import CrowdSim
+        if not self.batched:
+            return "batched = False"
+        if k <= 1:
+            return "k = 1"
+        if type(self.env) is not CrowdSim or self.env.__dict__.get("_vec") is None:
+            return "env is not the drop-in CrowdSim"
+        if self.env._vec.human_policy_name != "orca" or self.env._vec.robot is not self.robot:
+            return "humans are not ORCA / robot differs from the env's"
+        pol = self.robot.policy
+        if not stay and not hasattr(pol, "predict_batch"):
+            return "policy has no predict_batch"
+        if phase == "train" and getattr(pol, "trainable", False) and not stay:
+            eps = getattr(pol, "epsilon", None)
+            if eps is None or eps > 0:
+                return "train phase with epsilon-greedy exploration on the shared numpy stream"
+        if getattr(pol, "with_om", False):
+            return "occupancy maps"
+        if update_memory:
+            src = self.target_policy if imitation_learning else pol
+            if not hasattr(src, "transform_batch"):
+                return "policy has no transform_batch"
+            if not imitation_learning and self.target_model is None:
+                return "no target model"
+        return None
+
+    def _vec_explorer(self, E):
+        """The batched twin of the E = 1 env (built once per batch size): same configuration object, same robot, and
+        every attribute the reference's drivers assign on the env after configure() (`human_num`, `test_sim`, ...,
+        train.py:91, test.py:67-69) is taken over at each call; `case_counter` is the same dict, so the counters advance
+        on the E = 1 env exactly as the sequential loop would leave them."""
+        from ..envs.crowd_sim import CrowdSim
+        from ..rollout import VecExplorer
+        small = self.env._vec
+        cache = self.__dict__.setdefault("_vec_cache", {})
+        if E not in cache:
+            big = type(small)(E, small.device)
+            big.configure(small.config)
+            big.set_robot(self.robot)
+            cache[E] = VecExplorer(big, self.robot, device=self.device, gamma=self.gamma)
+        vex = cache[E]
+        big = vex.env
+        for name in CrowdSim._FORWARD:
+            if name != "robot":
+                setattr(big, name, getattr(small, name))
+        big._orca, big.count_hh = small._orca, small.count_hh
+        vex.policy, vex.robot, vex.gamma = self.robot.policy, self.robot, self.gamma
+        vex.memory, vex.target_policy, vex.target_model = self.memory, self.target_policy, self.target_model
+        vex.raw_memory, vex.rawob = self.raw_memory, self.rawob
+        return vex
+
     def run_k_episodes(self, k, phase, update_memory=False, imitation_learning=False, episode=None,
                        print_failure=False, update_raw_ob=False, stay=False, returnRate=True, test_case=None,
                        returnNav=False, cacheFile=None):
         self.robot.policy.set_phase(phase)
+        self.last_run_batched = self._batched_reason(k, phase, update_memory, imitation_learning, stay) is None
+        if self.last_run_batched:
+            vex = self._vec_explorer(min(int(k), int(self.max_batch_envs)))
+            return vex.run_k_episodes(k, phase, update_memory=update_memory, imitation_learning=imitation_learning,
+                                      episode=episode, print_failure=print_failure, returnRate=returnRate,
+                                      returnNav=returnNav, stay=stay, update_raw_ob=update_raw_ob, cacheFile=cacheFile,
+                                      test_case=test_case)
         outcome = {"success": [], "collision": [], "timeout": []}       # (episode index, time)
         too_close, min_dist, returns = 0, [], []
         fcount = 0

@@ -38,18 +38,35 @@ class Trainer(object):
 
     # ------------------------------------------------------------------ data parallel helpers
     @staticmethod
+    def _grouped():
+        return dist.is_available() and dist.is_initialized()
+
+    @staticmethod
     def _world():
-        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        return dist.get_world_size() if Trainer._grouped() else 1
+
+    @staticmethod
+    def _collective(fn, t):
+        """Run collective `fn` on tensor t where the backend can see it: RCCL ('nccl') works on device memory; under
+        gloo (CPU rehearsals, several ranks sharing one GPU in tests) device tensors make the trip through a host copy."""
+        if t.is_cuda and dist.get_backend() == "gloo":
+            h = t.cpu()
+            fn(h)
+            t.copy_(h)
+        else:
+            fn(t)
 
     def sync_weights(self, src=0):
         if self._world() > 1:
             for p in self.model.parameters():
-                dist.broadcast(p.data, src)
+                self._collective(lambda t: dist.broadcast(t, src), p.data)
 
     def _allreduce_grads(self):
-        ws = self._world()
-        if ws == 1:
+        # a process group of ONE rank still runs the collective (the world-size-1 RCCL test exercises exactly the
+        # call an N-rank job makes); without a group there is nothing to reduce
+        if not self._grouped():
             return
+        ws = self._world()
         params = [p for p in self.model.parameters() if p.grad is not None]
         n = sum(p.grad.numel() for p in params)
         if self._flat is None or self._flat.numel() != n or self._flat.device != params[0].grad.device:
@@ -59,8 +76,9 @@ class Trainer(object):
             k = p.grad.numel()
             self._flat[off:off + k].copy_(p.grad.reshape(-1))
             off += k
-        dist.all_reduce(self._flat)                 # one bucket, one collective
-        self._flat.div_(ws)
+        self._collective(dist.all_reduce, self._flat)          # one bucket, one collective
+        if ws > 1:
+            self._flat.div_(ws)
         off = 0
         for p in params:
             k = p.grad.numel()

@@ -117,3 +117,62 @@ def test_bench_two_ranks_through_the_drivers_launcher():
     assert "x2" in line["config"]["parallelism"]
     assert line["gathered_episode_records"] is not None and line["gathered_episode_records"] > 0
     assert line["value"] > 1e8 and line["cpu_baseline"] is None
+
+
+def _dp_children(ws, backend, mode, tmp_path, tag):
+    import torch
+    port = 32100 + (os.getpid() % 1500) + (7 if mode == "g10" else 0) + (3 if backend == "nccl" else 0)
+    outs = [str(tmp_path / ("%s_%d.pt" % (tag, r))) for r in range(ws)]
+    envv = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-m", "tests.dp_worker", str(r), str(ws), str(port), backend, mode, outs[r]],
+                              cwd=ROOT, env=envv, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(ws)]
+    logs = []
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    assert all(pr.returncode == 0 for pr in procs), "\n".join(l[-3000:] for l in logs)
+    return [torch.load(o, weights_only=True) for o in outs]
+
+
+@pytest.mark.parametrize("ws,backend", [(2, "gloo"), (1, "nccl")])
+def test_data_parallel_trainer_on_device_matches_reference_trainer(ws, backend, tmp_path, golden_dir):
+    """f2 on the device with ranks (crowd_nav/utils/trainer.py:64-82 + one flat-bucket gradient all-reduce per step):
+    the model, the memory shard and the gradient bucket live on cuda:0 in every rank.  The ranks split the memory of
+    the REFERENCE Trainer's own recorded run (g10_trainer.npz, `batch` mode) row by row, start from different weights
+    (sync_weights broadcasts rank 0's) and must end at the reference's weights: 2e-6, as the single-process device run.
+    world 2: two child processes sharing GPU 0, the collective on host copies (gloo); world 1: the same code path through
+    an `nccl` (= RCCL) group, i.e. the all-reduce runs on the device bucket itself."""
+    import numpy as np
+    res = _dp_children(ws, backend, "g10", tmp_path, "g10")
+    g = np.load(os.path.join(golden_dir, "g10_trainer.npz"))
+    assert all(r["backend"] == backend and r["world"] == ws for r in res)
+    assert sum(r["rows"] for r in res) == g["batch_states"].shape[0]
+    for r in res:
+        for k, v in r["weights"].items():
+            np.testing.assert_allclose(v.numpy(), g["batch_w1__" + k.replace(".", "__")], rtol=0, atol=2e-6, err_msg=k)
+    for k in res[0]["weights"]:
+        assert all(bool((r["weights"][k] == res[0]["weights"][k]).all()) for r in res), k        # ranks in lock step
+    # each rank's loss is the MSE over its own rows; their row-weighted mean is the reference's batch loss
+    n = [r["rows"] for r in res]
+    for i in range(3):
+        got = sum(r["losses"][i] * m for r, m in zip(res, n)) / sum(n)
+        assert abs(got - float(g["batch_losses"][i])) < 2e-6, (i, got)
+
+
+def test_data_parallel_trainer_on_device_unequal_shards(tmp_path):
+    """Two ranks on GPU 0 with 32 vs 45 rows (2 vs 3 mini-batches of 16): the epoch's step count is agreed by one
+    all-reduce(MAX), the short rank wraps around its permutation, and the weights stay identical on both ranks."""
+    import torch
+    res = _dp_children(2, "gloo", "unequal", tmp_path, "uneq")
+    assert [r["rows"] for r in res] == [32, 45]
+    from tests.test_training_cpu import _model
+    init = _model(seed=0).state_dict()
+    for k in res[0]["weights"]:
+        assert torch.equal(res[0]["weights"][k], res[1]["weights"][k]), k
+    assert not torch.equal(res[0]["weights"]["mlp1.0.weight"], init["mlp1.0.weight"])

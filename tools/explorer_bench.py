@@ -37,5 +37,50 @@ def main():
               "value targets), memory %d" % (upd, el * 1e3, E, el * 1e3 / 128, len(mem)))
 
 
+def dropin():
+    """What a reference driver gets after dropin.install(): crowd_nav.utils.explorer.Explorer on the E = 1 gym env,
+    `run_k_episodes(500, 'test')` with a SARL robot (test.py:109, train.py:249) -- handed to the batched VecExplorer --
+    against the same call kept on the sequential E = 1 loop (a few episodes, scaled)."""
+    from modelcrowdnav_amd import configs
+    from modelcrowdnav_amd.envs import CrowdSim
+    from modelcrowdnav_amd.envs.utils.robot import Robot
+    from modelcrowdnav_amd.utils.explorer import Explorer
+    dev = torch.device("cuda", 0)
+    cfg = configs.env_config(**{"sim.human_num": 5})
+    env = CrowdSim()
+    env.configure(cfg)
+    robot = Robot(cfg, "robot")
+    pol = bench._sarl_policy(dev, 0.25)
+    robot.set_policy(pol)
+    env.set_robot(robot)
+    pol.set_env(env)
+    ex = Explorer(env, robot, dev, gamma=0.9)
+    k = 500
+    ex.run_k_episodes(k, "test")                                   # builds the batched twin, loads code objects
+    env.case_counter["test"] = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out_b = ex.run_k_episodes(k, "test")
+    torch.cuda.synchronize()
+    tb = time.perf_counter() - t0
+    assert ex.last_run_batched
+    ex.batched = False
+    ks = 4
+    env.case_counter["test"] = 0
+    ex.run_k_episodes(1, "test")
+    env.case_counter["test"] = 0
+    t0 = time.perf_counter()
+    out_s = ex.run_k_episodes(ks, "test")
+    ts = time.perf_counter() - t0
+    print("drop-in Explorer.run_k_episodes(%d, 'test'), SARL robot, E = 1 gym env: batched %.3f s (%.2f ms per episode); "
+          "sequential %.3f s for %d episodes (%.1f ms per episode) -> %.0f x" %
+          (k, tb, tb / k * 1e3, ts, ks, ts / ks * 1e3, (ts / ks) / (tb / k)))
+    print("  returned (batched):    ", out_b)
+    print("  returned (sequential, first %d cases):" % ks, out_s)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "dropin":
+        dropin()
+    else:
+        main()

@@ -407,13 +407,34 @@ typedef struct mcn_tuning {
                               * dense launch (1) or solve them in the step kernel (0); -1: defer from 8 ORCA neighbours and 16 384 wavefronts */
 } mcn_tuning;
 
-/* NULL restores the initial values.  Returns MCN_EINVAL for out-of-range fields.  The settings are one unsynchronised
- * process-wide struct read at every launch: do not call mcn_set_tuning while another thread is launching. */
+/* NULL restores the initial values.  Returns MCN_EINVAL for out-of-range fields.  The settings are one process-wide
+ * struct; every launch takes a consistent snapshot of it under a lock, so mcn_set_tuning may be called while other
+ * threads launch (they see the old or the new settings, never a mixture). */
 int mcn_set_tuning(const mcn_tuning *t);
 int mcn_get_tuning(mcn_tuning *t);
 
 /* Library self-description (host). */
 const char *mcn_version(void);
+
+/*
+ * ABI guard.  MCN_ABI_VERSION changes whenever a struct of this header changes size or layout or an entry point
+ * changes its signature (0.3 grew mcn_tuning by lp3_defer and mcn_env_out by lp3_queue: ABI 4).  A caller built against
+ * another header must not pass structs to this library: compare mcn_abi_version() with the MCN_ABI_VERSION it was
+ * compiled with, and (bindings without the header: ctypes, cgo) mcn_sizeof() with the size of its own struct mirrors.
+ */
+#define MCN_ABI_VERSION 4
+int32_t mcn_abi_version(void);
+enum { MCN_SIZEOF_ENV_CFG = 0, MCN_SIZEOF_ENV_STATE = 1, MCN_SIZEOF_ENV_OUT = 2, MCN_SIZEOF_ROLLOUT = 3,
+       MCN_SIZEOF_TUNING = 4, MCN_SIZEOF_STEP_REC = 5, MCN_SIZEOF_ROLL_REC = 6, MCN_SIZEOF_SARL_NET = 7,
+       MCN_SIZEOF_SGAN_NET = 8, MCN_SIZEOF_SCENARIO_CFG = 9, MCN_SIZEOF_MLP_WORLD_NET = 10, MCN_SIZEOF_ATTN_WORLD_NET = 11 };
+int64_t mcn_sizeof(int32_t which);                 /* sizeof the struct named by MCN_SIZEOF_*; -1 for an unknown id */
+
+/*
+ * Diagnostic: the kernel family ("env_step_quad_kernel", "env_rollout_quad_kernel", "env_step_loop_kernel",
+ * "env_pair_kernel", "env_step_kernel") that the calling thread's latest mcn_env_step / mcn_env_rollout call
+ * dispatched to; "" before the first call.  bench.py attributes profiles to the kernel that really ran with it.
+ */
+const char *mcn_last_dispatch(void);
 
 #ifdef __cplusplus
 }

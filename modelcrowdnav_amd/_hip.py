@@ -146,13 +146,38 @@ def _load():
     lib.mcn_sgan_workspace_bytes.restype = C.c_int64
     lib.mcn_sgan_step.argtypes = [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _vp]
     lib.mcn_sgan_step.restype = C.c_int
+    lib.mcn_abi_version.restype = _i
+    lib.mcn_sizeof.argtypes, lib.mcn_sizeof.restype = [_i], C.c_int64
+    lib.mcn_last_dispatch.restype = C.c_char_p
+    _check_abi(lib)
     return lib
+
+
+ABI_VERSION = 4          # include/mcn.h: MCN_ABI_VERSION this binding's struct mirrors were written against
+
+
+def _check_abi(lib):
+    """A library built from another header must not receive these struct mirrors (include/mcn.h: ABI guard)."""
+    got = int(lib.mcn_abi_version())
+    if got != ABI_VERSION:
+        raise ImportError("modelcrowdnav_amd: %s has ABI %d, this binding was written for ABI %d -- rebuild the library "
+                          "(make -C modelcrowdnav_amd/csrc)" % (LIB_PATH, got, ABI_VERSION))
+    mirrors = {0: EnvCfg, 1: EnvState, 2: EnvOut, 3: Rollout, 4: Tuning, 5: StepRec, 6: RollRec, 9: ScenarioCfg}
+    for which, cls in mirrors.items():
+        if int(lib.mcn_sizeof(which)) != C.sizeof(cls):
+            raise ImportError("modelcrowdnav_amd: struct %s is %d bytes here, %d in %s" %
+                              (cls.__name__, C.sizeof(cls), int(lib.mcn_sizeof(which)), LIB_PATH))
+
+
+def last_dispatch():
+    """Kernel family the calling thread's latest mcn_env_step / mcn_env_rollout dispatched to (mcn_last_dispatch)."""
+    return lib.mcn_last_dispatch().decode()
 
 
 lib = _load()
 
 # every symbol include/mcn.h declares; tests/test_abi.py checks the .so exports each one
-EXPORTED = ["mcn_version", "mcn_set_tuning", "mcn_get_tuning", "mcn_env_step", "mcn_env_lp3_queue_bytes", "mcn_env_rollout", "mcn_scenario_pool", "mcn_orca_batch", "mcn_pack_linear", "mcn_sarl_workspace_bytes",
+EXPORTED = ["mcn_version", "mcn_abi_version", "mcn_sizeof", "mcn_last_dispatch", "mcn_set_tuning", "mcn_get_tuning", "mcn_env_step", "mcn_env_lp3_queue_bytes", "mcn_env_rollout", "mcn_scenario_pool", "mcn_orca_batch", "mcn_pack_linear", "mcn_sarl_workspace_bytes",
             "mcn_sarl_lookahead", "mcn_sarl_lookahead_env", "mcn_sarl_predict", "mcn_sgan_workspace_bytes", "mcn_sgan_step", "mcn_mlp_world_step", "mcn_attn_world_workspace_bytes",
             "mcn_attn_world_step"]
 
@@ -171,7 +196,7 @@ def get_tuning():
 def set_tuning(**kw):
     """Override kernel dispatch (tests, tuning): set_tuning(quad_max_envs=0, force_generic=1); no arguments =
     back to the initial (automatic / environment) values.  The given fields are laid over the CURRENT settings.
-    Returns the previous settings.  Process-wide and unsynchronised: not while another thread launches."""
+    Returns the previous settings.  Process-wide; launches snapshot the settings under the library's lock."""
     prev = get_tuning()
     if not kw:
         check(lib.mcn_set_tuning(None), "mcn_set_tuning")

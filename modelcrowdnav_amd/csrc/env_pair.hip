@@ -28,6 +28,7 @@
 #include "env_common.hpp"
 
 namespace mcn {
+void note_dispatch(const char *family);          // mcn_api.hip: mcn_last_dispatch()
 
 __device__ __forceinline__ long long d2ll(double v) { return __builtin_bit_cast(long long, v); }
 __device__ __forceinline__ double ll2d(long long v) { return __builtin_bit_cast(double, v); }
@@ -280,6 +281,7 @@ bool launch_env_pair(const StepParams &p, hipStream_t stream)
         case 10: launch_pair_one<10>(p, stream); break;
         default: return false;
     }
+    note_dispatch("env_pair_kernel");
     return true;
 }
 

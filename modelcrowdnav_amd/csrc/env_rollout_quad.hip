@@ -20,6 +20,7 @@
 #include "env_common.hpp"
 
 namespace mcn {
+void note_dispatch(const char *family);          // mcn_api.hip: mcn_last_dispatch()
 
 // Diagnostic build only (make -C modelcrowdnav_amd/csrc stamp -> build_stamp/libmcn_hip.so, tools/fixed_cost.py):
 // lane 0 of every wavefront writes the 100 MHz real-time counter at kernel entry (slot 0), after the state load
@@ -453,6 +454,7 @@ bool launch_env_rollout_quad(const StepParams &p, int T, hipStream_t stream)
         case 10: launch_rollout_one<5, 0>(p, T, stream); break;
         default: return false;
     }
+    note_dispatch("env_rollout_quad_kernel");
     return true;
 }
 

@@ -30,6 +30,7 @@
 #include "lp3_queue.hpp"
 
 namespace mcn {
+void note_dispatch(const char *family);          // mcn_api.hip: mcn_last_dispatch()
 
 // crowds up to this size pre-filter the human-human overlaps inside the ORCA candidate loop (squared distances, no
 // sqrt); larger ones keep the separate loop: the extra live values push their unrolled solver past 168 VGPRs
@@ -604,6 +605,7 @@ static void launch_one(const StepParams &p, int blocks, hipStream_t stream)
 {
     const size_t sm = step_smem_bytes(BLOCK, MODE != MCN_HUMANS_ORCA ? 0 : (NT ? NT / 2 : p.nl_cap),
                                       MODE == MCN_HUMANS_ORCA && NT > 0 && NT - 1 + VIS >= 5 && BLOCK == 64);
+    note_dispatch("env_step_kernel");
     hipLaunchKernelGGL((env_step_kernel<BLOCK, NT, VIS, MODE, HH_T>), dim3(blocks), dim3(BLOCK), sm, stream, p);
 }
 
@@ -659,6 +661,7 @@ bool launch_env_step_loop(const StepParams &p, int T, hipStream_t stream)
     q.lp3_defer = 0;
     q.G = G;
     const size_t sm = step_smem_bytes(64, p.N / 2, nc >= 5);
+    note_dispatch("env_step_loop_kernel");
 #define MCN_LOOP_CASE(NT_) case NT_: \
         if (p.cfg.robot_visible) hipLaunchKernelGGL((env_step_loop_kernel<NT_, 1>), dim3(waves_total), dim3(64), sm, stream, q, T); \
         else                     hipLaunchKernelGGL((env_step_loop_kernel<NT_, 0>), dim3(waves_total), dim3(64), sm, stream, q, T); \

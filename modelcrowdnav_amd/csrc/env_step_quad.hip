@@ -25,6 +25,7 @@
 #include "env_common.hpp"
 
 namespace mcn {
+void note_dispatch(const char *family);          // mcn_api.hip: mcn_last_dispatch()
 
 // SPLIT = true: the workgroup has two wavefronts working on the same G envs.  Wavefront 0 solves ORCA (float32),
 // wavefront 1 does the float64 swept-circle / overlap tests, the reward ladder and all per-env outputs AT THE
@@ -280,6 +281,7 @@ bool launch_env_step_quad(const StepParams &p, hipStream_t stream)
         case 10: launch_quad_one<5, 0>(p, stream); break;
         default: return false;
     }
+    note_dispatch("env_step_quad_kernel");
     return true;
 }
 

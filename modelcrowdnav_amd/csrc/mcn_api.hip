@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <stdlib.h>
+#include <mutex>
 #include "../../include/mcn.h"
 
 #include "env_step_params.hpp"
@@ -46,6 +47,7 @@ int read_counts(void *dst, size_t bytes, int reset);
 // launch needs them, as the initial values; after that only mcn_set_tuning changes them.  No getenv on the launch path.
 static mcn_tuning g_tuning;
 static bool g_tuning_init = false;
+static std::mutex g_tuning_mu;          // launches copy the settings under it: a concurrent mcn_set_tuning never tears them
 static int env_or(const char *name, int dflt)
 {
     const char *v = getenv(name);
@@ -65,10 +67,36 @@ static mcn_tuning tuning_from_env()
     t.lp3_defer = env_or("MCN_LP3_DEFER", -1);
     return t;
 }
-static const mcn_tuning &tuning()
+static mcn_tuning tuning()
 {
+    std::lock_guard<std::mutex> lock(g_tuning_mu);
     if (!g_tuning_init) { g_tuning = tuning_from_env(); g_tuning_init = true; }
     return g_tuning;
+}
+
+// mcn_last_dispatch(): the launch functions of the env kernels note which family they picked (per host thread).
+static thread_local const char *g_last_dispatch = "";
+namespace mcn { void note_dispatch(const char *family) { g_last_dispatch = family; } }
+const char *mcn_last_dispatch(void) { return g_last_dispatch; }
+
+int32_t mcn_abi_version(void) { return MCN_ABI_VERSION; }
+int64_t mcn_sizeof(int32_t which)
+{
+    switch (which) {
+        case MCN_SIZEOF_ENV_CFG: return sizeof(mcn_env_cfg);
+        case MCN_SIZEOF_ENV_STATE: return sizeof(mcn_env_state);
+        case MCN_SIZEOF_ENV_OUT: return sizeof(mcn_env_out);
+        case MCN_SIZEOF_ROLLOUT: return sizeof(mcn_rollout);
+        case MCN_SIZEOF_TUNING: return sizeof(mcn_tuning);
+        case MCN_SIZEOF_STEP_REC: return sizeof(mcn_step_rec);
+        case MCN_SIZEOF_ROLL_REC: return sizeof(mcn_roll_rec);
+        case MCN_SIZEOF_SARL_NET: return sizeof(mcn_sarl_net);
+        case MCN_SIZEOF_SGAN_NET: return sizeof(mcn_sgan_net);
+        case MCN_SIZEOF_SCENARIO_CFG: return sizeof(mcn_scenario_cfg);
+        case MCN_SIZEOF_MLP_WORLD_NET: return sizeof(mcn_mlp_world_net);
+        case MCN_SIZEOF_ATTN_WORLD_NET: return sizeof(mcn_attn_world_net);
+        default: return -1;
+    }
 }
 
 // Validates one env-step problem and fills the kernel argument block.  Shared by mcn_env_step / mcn_env_rollout.
@@ -107,7 +135,7 @@ static int fill_step_params(mcn::StepParams &p, const mcn_env_cfg *cfg, const mc
     // E <= 8192 at 5 humans); above that the lane-per-human kernel wins on throughput.  Inside the quad
     // kernel, ORCA and the float64 pairwise work go to two cooperating wavefronts only while BOTH still get a
     // SIMD of their own (grid <= 512 workgroups).  mcn_set_tuning overrides (tests, tuning).
-    const mcn_tuning &tu = tuning();
+    const mcn_tuning tu = tuning();
     p.force_generic = tu.force_generic > 0 ? 1 : 0;
     p.pair_stream = tu.pair_stream;
     p.step_block = tu.step_block;
@@ -132,6 +160,7 @@ const char *mcn_version(void) { return "modelcrowdnav_amd 0.3 (gfx950)"; }
 
 int mcn_set_tuning(const mcn_tuning *t)
 {
+    std::lock_guard<std::mutex> lock(g_tuning_mu);
     if (!t) { g_tuning = tuning_from_env(); g_tuning_init = true; return MCN_OK; }
     if (t->quad_split > 1 || t->rollout_fused > 1 || t->rollout_split > 1 || t->pair_stream > 3 || t->force_generic < 0 || t->force_generic > 1) return MCN_EINVAL;
     if (t->quad_max_envs < -1 || t->quad_split < -1 || t->rollout_fused < -1 || t->rollout_split < -1 || t->pair_stream < -1) return MCN_EINVAL;
@@ -181,7 +210,7 @@ int mcn_env_rollout(const mcn_env_cfg *cfg, const mcn_env_state *st, const doubl
     // 2.7x.  Two cooperating wavefronts per env group while the doubled grid still finds idle issue slots (measured:
     // wins up to 1536 groups = 4608 envs, loses from 1707).
     // mcn_set_tuning (rollout_fused / rollout_split) overrides (tests, tuning).
-    const mcn_tuning &tu = tuning();
+    const mcn_tuning tu = tuning();
     const int envs_per_wave = 64 / (4 * N) > 0 ? 64 / (4 * N) : 1;
     const long waves = ((long)E + envs_per_wave - 1) / envs_per_wave;
     const bool fused = tu.rollout_fused >= 0 ? tu.rollout_fused != 0 : waves <= 14000;

@@ -253,6 +253,17 @@ class _MlpWorldNet(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4")]
 
 
+def _weights_stamp(module):
+    """Changes whenever a parameter of `module` is written in place (optimizer steps, load_state_dict, .copy_) or
+    replaced (another tensor object / device move): what the packed HIP fragments were made from."""
+    return tuple((id(p), p.data_ptr(), p._version) for p in module.parameters())
+
+
+def _dropout_active(module):
+    """A module left in train() mode with a Dropout of p > 0 draws masks; the HIP kernels are eval-mode forwards."""
+    return module.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in module.modules())
+
+
 def pack_mlp_world(module, num_human, dev):
     """MlpWorld.state_dict -> (ctypes mcn_mlp_world_net, [device tensors kept alive]); layouts in include/mcn.h."""
     from .. import _hip
@@ -286,13 +297,17 @@ def pack_mlp_world(module, num_human, dev):
 
 class VecMlpWorld(object):
     """MlpWorld as a VecModelCrowdSim `sim_world`: one mcn_mlp_world_step launch for all E scenes (eval mode: the
-    reference calls the model under `model_sim.eval()` when it imagines, train_model_based_sgan.py).  The weights are
-    packed at construction; call `refresh()` after training steps changed the module."""
+    reference calls the model under `model_sim.eval()` when it imagines, train_model_based_sgan.py).  The packed weight
+    fragments follow the module: they are re-packed whenever a parameter changed since they were made (training rounds
+    alternate with imagination on the same module, train_model_based.py) -- `refresh()` is never needed.  A module left
+    in train() mode with active Dropout is NOT an eval-mode forward: that call goes through the torch module instead
+    (same masks / random stream as the E = 1 path)."""
 
     def __init__(self, module, env):
         self.module, self.env = module, env
         self._net = None
         self.out_vel = None
+        self._torch = None
 
     def refresh(self):
         self._net = None
@@ -301,9 +316,14 @@ class VecMlpWorld(object):
         from .. import _hip
         env = self.env
         E, N, dev = env.num_envs, env._alloc_N, env.device
-        if self._net is None or self._net[2] != (E, N):
+        if _dropout_active(self.module):
+            if self._torch is None:
+                self._torch = VecTorchWorld(self.module, env)
+            return self._torch(hpos, noise)
+        stamp = _weights_stamp(self.module)
+        if self._net is None or self._net[2] != (E, N) or self._net[3] != stamp:
             net, keep = pack_mlp_world(self.module, N, dev)
-            self._net = (net, keep, (E, N))
+            self._net = (net, keep, (E, N), stamp)
             self.out_vel = torch.empty(E, N, 2, dtype=torch.float64, device=dev)
         rc = _hip.lib.mcn_mlp_world_step(C.byref(self._net[0]), _hip.ptr(env.hpos), _hip.ptr(env.hvel),
                                          _hip.ptr(self.out_vel), E, N, _hip.stream_ptr(dev))
@@ -362,9 +382,9 @@ def pack_attn_world(module, dev):
 
 
 class VecAttnWorld(object):
-    """AttentionWorld as a VecModelCrowdSim `sim_world`: one mcn_attn_world_step launch for all E scenes.  The weights
-    are packed at construction; call `refresh()` after training steps changed the module.  `hcount` ([E] int32
-    device tensor): scene e has only its first hcount[e] pedestrians."""
+    """AttentionWorld as a VecModelCrowdSim `sim_world`: one mcn_attn_world_step launch for all E scenes.  The packed
+    weight fragments follow the module (re-packed whenever a parameter changed since they were made; `refresh()` is never
+    needed).  `hcount` ([E] int32 device tensor): scene e has only its first hcount[e] pedestrians."""
 
     def __init__(self, module, env):
         self.module, self.env = module, env
@@ -378,10 +398,13 @@ class VecAttnWorld(object):
         from .. import _hip
         env = self.env
         E, N, dev = env.num_envs, env._alloc_N, env.device
-        if self._net is None or self._net[2] != (E, N):
+        if _dropout_active(self.module):
+            raise RuntimeError("AttentionWorld in train() mode with active Dropout: the HIP kernel is an eval-mode forward")
+        stamp = _weights_stamp(self.module)
+        if self._net is None or self._net[2] != (E, N) or self._net[4] != stamp:
             net, keep = pack_attn_world(self.module, dev)
             ws = torch.empty(_hip.lib.mcn_attn_world_workspace_bytes(E, N) // 4, dtype=torch.float32, device=dev)
-            self._net = (net, keep, (E, N), ws)
+            self._net = (net, keep, (E, N), ws, stamp)
             self.out_vel = torch.zeros(E, N, 2, dtype=torch.float64, device=dev)
         rc = _hip.lib.mcn_attn_world_step(C.byref(self._net[0]), _hip.ptr(env.hpos), _hip.ptr(env.hvel), _hip.ptr(hcount),
                                           _hip.ptr(self._net[3]), _hip.ptr(self.out_vel), E, N, _hip.stream_ptr(dev))

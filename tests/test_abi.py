@@ -87,3 +87,24 @@ def test_more_bad_arguments_are_rejected_on_host():
     assert _hip.lib.mcn_sgan_step(None, fake, 0, 1, None, fake, None, fake, fake, None, 0.25, 4, 5, None) == _hip.MCN_EINVAL
     r = _hip.Rollout()
     assert ctypes.sizeof(_hip.ScenarioCfg) == 10 * 8 + 2 * 4
+
+
+def test_abi_version_and_struct_sizes_are_checked_against_the_library():
+    """include/mcn.h's ABI guard: the library reports the ABI it was built with and the size of every struct of the
+    header; the binding refuses a library of another ABI at import (no GPU needed for either call)."""
+    import pytest
+    from modelcrowdnav_amd import _hip
+    hdr = open(os.path.join(ROOT, "include", "mcn.h")).read()
+    want = int(re.search(r"#define\s+MCN_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert _hip.lib.mcn_abi_version() == want == _hip.ABI_VERSION
+    for which, cls in {0: _hip.EnvCfg, 1: _hip.EnvState, 2: _hip.EnvOut, 3: _hip.Rollout, 4: _hip.Tuning, 5: _hip.StepRec,
+                       6: _hip.RollRec, 9: _hip.ScenarioCfg}.items():
+        assert _hip.lib.mcn_sizeof(which) == ctypes.sizeof(cls), cls.__name__
+    assert _hip.lib.mcn_sizeof(7) > 0 and _hip.lib.mcn_sizeof(8) > 0 and _hip.lib.mcn_sizeof(99) == -1
+
+    class Old(object):                                   # a library built from an older header
+        def mcn_abi_version(self):
+            return want - 1
+    with pytest.raises(ImportError):
+        _hip._check_abi(Old())
+    assert _hip.last_dispatch() == ""                    # nothing launched in this process yet

@@ -434,6 +434,77 @@ def test_rollout_bench_configuration_equals_single_steps():
     assert int(a.rollout_buffers["fin_count"].sum().item()) > 10000
 
 
+def _oracle_with_pool_restarts(env_ids, pool, N, acts_np, T, env_for_cfg):
+    """The oracle stepping the sampled envs through the bench workload: on done the env restarts from the scenario pool
+    exactly as the in-kernel reset does (mcn.h mcn_rollout: humans <- pool[next_case], zero velocity, first-arrival
+    times cleared, robot back to its start pose, clock 0, next_case += case_stride mod pool_size)."""
+    from modelcrowdnav_amd.envs import scenarios as S
+    n = len(env_ids)
+    st = cport.EnvState(n, N)
+
+    def load(rows, cases):
+        sc = pool[cases]
+        st.hpx[rows], st.hpy[rows], st.hgx[rows], st.hgy[rows] = sc[..., S.PX], sc[..., S.PY], sc[..., S.GX], sc[..., S.GY]
+        st.hvx[rows], st.hvy[rows] = sc[..., S.VX], sc[..., S.VY]
+        st.hr[rows], st.hvpref[rows] = sc[..., S.RAD], sc[..., S.VPREF]
+        st.human_times[rows] = 0
+        rr = env_for_cfg.spec().robot_row()
+        st.rpx[rows], st.rpy[rows], st.rgx[rows], st.rgy[rows] = rr[S.PX], rr[S.PY], rr[S.GX], rr[S.GY]
+        st.rvx[rows], st.rvy[rows], st.rr[rows], st.gtime[rows] = 0.0, 0.0, rr[S.RAD], 0.0
+    load(np.arange(n), env_ids % 500)
+    next_case = (env_ids + 1) % 500
+    cfg = H.oracle_cfg_for(env_for_cfg)
+    episodes = 0
+    for t in range(T):
+        a = acts_np[t][env_ids]
+        ref = cport.env_step(cfg, st, a[:, 0].copy(), a[:, 1].copy(), update=True)
+        d = np.nonzero(ref["done"])[0]
+        if len(d):
+            load(d, next_case[d])
+            next_case[d] = (next_case[d] + 1) % 500
+            episodes += len(d)
+    return st, ref, episodes
+
+
+@pytest.mark.parametrize("N,T", [(5, 1000), (10, 500)])
+def test_bench_timed_launch_shapes_against_single_steps_and_oracle(N, T):
+    """bench.py's timed configuration ITSELF: 4096 envs from bench.build_env (500-case pool, in-kernel restarts, Explorer
+    records), the driver's 20-step table-action sequence repeated to ONE 1000-step mcn_env_rollout launch (N = 5:
+    env_rollout_quad_kernel, state in registers) / ONE 500-step looped launch (N = 10: env_step_loop_kernel) -- against
+    (a) one mcn_env_step launch per step, every byte of state and records, and (b) the C oracle's trajectory of 64
+    sampled envs with the pool restarts replayed on the host, bit for bit."""
+    torch = _torch()
+    import bench
+    dev = torch.device("cuda", 0)
+    E, K = 4096, 20
+    acts = bench.make_actions(5 + K, E, E, 0, dev)[5:].repeat(T // K, 1, 1).contiguous()     # bench.py: acts_rep
+    assert acts.shape[0] == T
+    a, pool = bench.build_env(E, N, 0, dev)
+    b, _ = bench.build_env(E, N, 0, dev)
+    a.rollout(acts)                                           # ONE launch of T steps
+    for t in range(T):
+        b.step(acts[t])
+    torch.cuda.synchronize()
+    for k in ("hpos", "hvel", "hgoal", "hrad", "hvpref", "rpos", "rvel", "rgoal", "gtime", "step_rec"):
+        assert np.array_equal(getattr(a, k).cpu().numpy().view(np.uint8), getattr(b, k).cpu().numpy().view(np.uint8)), k
+    for k in ("state", "fin_return", "fin_time", "fin_info"):
+        assert np.array_equal(a.rollout_buffers[k].cpu().numpy().view(np.uint8),
+                              b.rollout_buffers[k].cpu().numpy().view(np.uint8)), k
+    assert int(a.rollout_buffers["fin_count"].sum().item()) > 4 * E
+    # (b) the oracle on 64 envs spread over the batch
+    ids = np.arange(64) * 64 + (np.arange(64) % 7)
+    st, ref, episodes = _oracle_with_pool_restarts(ids, pool, N, acts.cpu().numpy(), T, a)
+    assert episodes > 4 * 64
+    got = {k: getattr(a, k).cpu().numpy()[ids] for k in ("hpos", "hvel", "hgoal", "hrad", "rpos", "rvel", "gtime")}
+    assert np.array_equal(got["hpos"][..., 0], st.hpx) and np.array_equal(got["hpos"][..., 1], st.hpy)
+    assert np.array_equal(got["hvel"][..., 0], st.hvx) and np.array_equal(got["hvel"][..., 1], st.hvy)
+    assert np.array_equal(got["hgoal"][..., 0], st.hgx) and np.array_equal(got["hrad"], st.hr)
+    assert np.array_equal(got["rpos"][:, 0], st.rpx) and np.array_equal(got["rpos"][:, 1], st.rpy)
+    assert np.array_equal(got["rvel"][:, 0], st.rvx) and np.array_equal(got["gtime"], st.gtime)
+    assert np.array_equal(a.reward.cpu().numpy()[ids], ref["reward"]) and np.array_equal(a.done.cpu().numpy()[ids], ref["done"])
+    assert np.array_equal(a.info.cpu().numpy()[ids], ref["info"]) and np.array_equal(a.dmin.cpu().numpy()[ids], ref["dmin"])
+
+
 def test_rollout_launch_matches_oracle_trajectory():
     """The fused T-step launch against the C oracle stepped T times (no pool: finished envs keep stepping, which the
     oracle does too)."""
@@ -604,3 +675,32 @@ def test_config5_shape_32768x10_exact_and_shard_invariant():
     parts = np.concatenate([s_.hpos.cpu().numpy() for s_ in shards], 0)
     assert np.array_equal(whole, parts)
     assert np.array_equal(env.rpos.cpu().numpy(), np.concatenate([s_.rpos.cpu().numpy() for s_ in shards], 0))
+
+
+def test_bench_kernel_attribution_matches_the_dispatcher():
+    """bench.expected_kernel() decides which profile rows (PMC traffic, SQ counters) a roofline entry is built from; it
+    re-states the library's dispatch rules in Python.  Every launch shape bench.py reports is launched here once and the
+    family the dispatcher REALLY took (mcn_last_dispatch) must be the one bench names."""
+    torch = _torch()
+    import bench
+    from modelcrowdnav_amd import _hip
+    dev = torch.device("cuda", 0)
+    for E, N, spl in [(4096, 5, 1), (4096, 5, 20), (4096, 5, 1000), (4096, 10, 1), (4096, 10, 500), (32768, 10, 1),
+                      (1 << 16, 5, 1), (1 << 18, 10, 1)]:
+        env, _ = bench.build_env(E, N, 0, dev)
+        acts = bench.make_actions(2, E, E, 0, dev)
+        if spl > 1:
+            env.rollout(acts)
+        else:
+            env.step(acts[0])
+        torch.cuda.synchronize()
+        assert _hip.last_dispatch() == bench.expected_kernel(E, N, False, spl), (E, N, spl, _hip.last_dispatch())
+        del env
+    for E, N in [(4096, 5), (1 << 18, 5), (1 << 17, 10)]:                   # the given-velocity (pairwise) sweep
+        env, _ = bench.build_env(E, N, 0, dev)
+        env.count_hh = False
+        acts = bench.make_actions(1, E, E, 0, dev)
+        env.step(acts[0], given_v=torch.zeros(E, N, 2, dtype=torch.float64, device=dev))
+        torch.cuda.synchronize()
+        assert _hip.last_dispatch() == bench.expected_kernel(E, N, True, 1), (E, N, _hip.last_dispatch())
+        del env

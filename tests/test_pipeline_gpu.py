@@ -101,6 +101,54 @@ def test_mlp_world_kernel_matches_torch_module(N):
     assert torch.allclose(moved[live], (got * env.time_step)[live], atol=1e-12)
 
 
+@pytest.mark.parametrize("kind", ["mlp", "attention"])
+def test_world_kernels_follow_the_module_through_training_steps(kind):
+    """train_model_based.py alternates Trainer_Sim.optimize_epoch with imagination on the SAME module: after an optimizer
+    step (and after load_state_dict) the HIP adapters must imagine with the new weights without a manual refresh(); and a
+    MlpWorld left in train() mode (Dropout 0.5 active, as before the first optimize_epoch) must not silently get the
+    kernel's eval-mode forward."""
+    import torch
+    from modelcrowdnav_amd.envs import VecModelCrowdSim
+    from modelcrowdnav_amd.policy.world_model import AttentionWorld, MlpWorld, VecTorchWorld, vec_world
+    from tests import helpers as H
+    E, N = 200, 5
+    dev = torch.device("cuda", 0)
+    env = H.make_vec_env(E, N, cls=VecModelCrowdSim)
+    H.upload(env, H.random_state(np.random.RandomState(2), E, N))
+    torch.manual_seed(3)
+    world = (MlpWorld(N) if kind == "mlp" else AttentionWorld()).to(dev).eval()
+    fast, slow = vec_world(world, env), VecTorchWorld(world, env)
+    assert type(fast).__name__ in ("VecMlpWorld", "VecAttnWorld")
+    v0 = fast(env.hpos).clone()
+    assert float((v0 - slow(env.hpos)).abs().max()) <= 1e-5
+    # one Adam step on a made-up target (what Trainer_Sim.optimize_epoch does to the module, trainer_sim.py:60-75)
+    opt = torch.optim.Adam(world.parameters(), lr=0.05)
+    world.train()
+    x = torch.cat([env.hpos, env.hvel], 2).reshape(E, -1).float()
+    loss = (world(x) - 0.3).pow(2).mean()
+    loss.backward()
+    opt.step()
+    world.eval()
+    v1 = fast(env.hpos).clone()                     # no refresh()
+    want1 = slow(env.hpos)
+    assert float((v1 - want1).abs().max()) <= 1e-5
+    assert float((v1 - v0).abs().max()) > 1e-3, "the step must have changed the predictions"
+    # load_state_dict replaces the values in place
+    torch.manual_seed(9)
+    other = (MlpWorld(N) if kind == "mlp" else AttentionWorld()).to(dev)
+    world.load_state_dict(other.state_dict())
+    assert float((fast(env.hpos) - slow(env.hpos)).abs().max()) <= 1e-5
+    if kind == "mlp":
+        world.train()                               # Dropout(0.5) draws masks now: not the kernel's function
+        torch.manual_seed(4)
+        a = fast(env.hpos).clone()
+        torch.manual_seed(4)
+        b = slow(env.hpos)
+        assert torch.equal(a, b)                    # the adapter went through the module, same random stream
+        world.eval()
+        assert float((fast(env.hpos) - slow(env.hpos)).abs().max()) <= 1e-5
+
+
 @pytest.mark.parametrize("N", [5, 1, 10, 7])
 def test_attention_world_kernel_matches_torch_module(N):
     """mcn_attn_world_step (world_attn.hip) against AttentionWorld.forward (crowd_nav/policy/world_model.py:54-106):

@@ -142,6 +142,19 @@ struct WeightStage {
     int tid;          // threadIdx.x, 0 .. kStageThreads-1
 };
 
+// MCN_DENSE_PIPE = 1 (default): the chunk loop below is software-pipelined by hand.  Left to itself the compiler
+// issues the ds_read_b128 pair of an 8-MFMA group right before that group's MFMAs (it reuses the registers of the
+// previous fragments, so the reads cannot start earlier) and the wavefront sits out an LDS round trip (~100+ cycles)
+// per 256 cycles of matrix work: a lone wavefront reaches ~75 % of the pipe and two of them still leave 10 % idle
+// (round-3 phase table: 100-wide layers at 2.2 x their MFMA time).  Here the A fragments live in a two-slot register
+// ring: the reads of group g + 1 are issued BEFORE the eight MFMAs of group g (256 cycles of cover), across output
+// tile pairs and across staged chunks; __builtin_amdgcn_sched_barrier(0) keeps the scheduler from sinking them back.
+// The chunk barrier sits before the LAST group of a chunk (all reads of the chunk have been issued and have
+// returned by then), so the next chunk's first fragments are fetched under that group's MFMAs as well.
+#ifndef MCN_DENSE_PIPE
+#define MCN_DENSE_PIPE 1
+#endif
+
 // LAST / LAST2: k-steps actually needed in the last / second-to-last input tile (ragged tiles packed "q first",
 // see mcn_pack_linear): the skipped steps would multiply zeros.
 template <int KT, int NT, bool RELU, bool HAS_INIT, int LAST = 4, int LAST2 = 4>
@@ -160,7 +173,37 @@ __device__ __forceinline__ void dense_staged(const f32x4 (&in)[KT], const f32x4 
     // exactly what global_load_lds writes (wave-uniform LDS base + lane * 16 B), so the weights go L2 -> LDS
     // without passing through (and pinning) VGPRs.  Biases ride along in a small tail region so that no ordinary
     // global load sits between a DMA and the barrier that retires it.
-    const int wave_base = S.tid & ~63;
+    const int wave_base = S.tid & ~63; (void)wave_base;
+#if MCN_DENSE_PIPE
+    // straight-line staging: every thread issues every DMA (a chunk is a whole number of 256-thread rounds); the source
+    // index of the ragged last chunk / of bias slots beyond the layer is clamped, the duplicates land in stage slots
+    // nobody reads.  No exec-mask branches: the DMA issue can sit between the MFMAs of a group.
+    static_assert(CH % kStageThreads == 0 || NCH == 1, "a staged chunk is a whole number of DMA rounds");
+    auto stage = [&](int c, int b) {
+        // (opaque copy: the per-lane addresses are derived here, a few integer instructions per DMA, instead of being
+        //  hoisted out of the tile loop as dozens of live 64-bit values)
+        int tid_ = S.tid;
+        asm volatile("" : "+v"(tid_));
+        const int wave_base = tid_ & ~63;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            int i = c * CH + tid_ + k * kStageThreads;
+            if ((c + 1) * CH > TOTAL || CH % kStageThreads != 0) i = i < TOTAL - 1 ? i : TOTAL - 1;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(wf + i),
+                (__attribute__((address_space(3))) void *)(S.buf + b * (kStageFloat4 + kStageBias) + k * kStageThreads + wave_base),
+                16, 0, 0);
+        }
+        if (!HAS_INIT) {
+            int i = c * BCH + tid_;
+            i = i < NT * 64 - 1 ? i : NT * 64 - 1;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(bf + i),
+                (__attribute__((address_space(3))) void *)(S.buf + b * (kStageFloat4 + kStageBias) + kStageFloat4 + wave_base),
+                16, 0, 0);
+        }
+    };
+#else
     auto stage = [&](int c, int b) {
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -177,8 +220,81 @@ __device__ __forceinline__ void dense_staged(const f32x4 (&in)[KT], const f32x4 
                 (__attribute__((address_space(3))) void *)(S.buf + b * (kStageFloat4 + kStageBias) + kStageFloat4 + wave_base),
                 16, 0, 0);
     };
+#endif
     stage(0, 0);
     __syncthreads();                                      // drains vmcnt (the DMA) and orders it before the reads
+#if MCN_DENSE_PIPE
+    // flattened (output tile pair, input tile) groups of the whole layer, eight MFMAs each
+    constexpr int PAIRS = (kChunkTiles + 1) / 2;          // tile pairs per staged chunk
+    constexpr int NP = (NT + 1) / 2;                      // tile pairs of the layer
+    constexpr int NG = NP * KT;
+    float4 ra[2], rb[2], ba = make_float4(0, 0, 0, 0), bb = make_float4(0, 0, 0, 0);
+    rb[0] = rb[1] = make_float4(0, 0, 0, 0);
+    auto issue = [&](int g) {                             // LDS -> register ring slot g & 1 (and the pair's biases)
+        const int pr = g / KT, t = g - pr * KT;
+        const int c = pr / PAIRS, h2 = 2 * (pr - c * PAIRS), n = 2 * pr;
+        const float4 *wc = S.buf + (c & 1) * (kStageFloat4 + kStageBias);
+        const float4 *w = wc + h2 * KT * 64;
+        ra[g & 1] = w[t * 64 + lane];
+        if (n + 1 < NT) rb[g & 1] = w[(KT + t) * 64 + lane];
+        if (t == 0 && !HAS_INIT) {
+            const float4 *bc = wc + kStageFloat4;
+            ba = bc[h2 * 64 + lane];
+            if (n + 1 < NT) bb = bc[(h2 + 1) * 64 + lane];
+        }
+    };
+    issue(0);
+    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int pr = g / KT, t = g - pr * KT;
+        const int c = pr / PAIRS, n = 2 * pr;
+        const bool two = (n + 1 < NT);
+        const bool chunk_first = (t == 0) && (pr == c * PAIRS);
+        // last group that reads chunk c: the chunk's last pair (or the layer's), last input tile
+        const bool chunk_last = (t == KT - 1) && ((pr == c * PAIRS + PAIRS - 1) || (pr == NP - 1));
+        if (chunk_last) __syncthreads();      // every read of chunk c has been issued (and is back: the data of THIS
+                                              // group is awaited here); the next chunk's DMA has landed
+        if (t == 0) {
+            if (HAS_INIT) { a0 = init[n]; if (two) a1 = init[n + 1]; }
+            else { a0 = (f32x4){ba.x, ba.y, ba.z, ba.w}; if (two) a1 = (f32x4){bb.x, bb.y, bb.z, bb.w}; }
+        }
+        const float4 w0 = ra[g & 1], w1 = rb[g & 1];
+        const int steps = (t == KT - 1) ? LAST : ((t == KT - 2) ? LAST2 : 4);
+        // The group's first MFMA comes BEFORE the next group's reads are issued: the compiler cannot count LDS reads
+        // individually while an LDS-DMA is in flight (it models global_load_lds as a FLAT access, after which every
+        // LDS wait is lgkmcnt(0)), so the wait for this group's fragments must not see the next group's reads yet.
+        // This group's fragments were requested seven MFMAs (~230 cycles) ago: the wait is free.
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, in[t][0], a0, 0, 0, 0);
+        if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, in[t][0], a1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < NG) issue(g + 1);
+        if (chunk_first && c + 1 < NCH) stage(c + 1, (c + 1) & 1);          // DMA of the next chunk, other buffer
+        __builtin_amdgcn_sched_barrier(0);
+        if (steps > 1) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, in[t][1], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, in[t][1], a1, 0, 0, 0);
+        }
+        if (steps > 2) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, in[t][2], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, in[t][2], a1, 0, 0, 0);
+        }
+        if (steps > 3) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, in[t][3], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, in[t][3], a1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t == KT - 1) {
+            if (RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a0[r] = relu_f32(a0[r]); a1[r] = relu_f32(a1[r]); }
+            }
+            out[n] = a0;
+            if (two) out[n + 1] = a1;
+        }
+    }
+#else
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         if (c + 1 < NCH) stage(c + 1, (c + 1) & 1);
@@ -229,6 +345,7 @@ __device__ __forceinline__ void dense_staged(const f32x4 (&in)[KT], const f32x4 
         }
         __syncthreads();
     }
+#endif
 }
 
 }  // namespace mcn

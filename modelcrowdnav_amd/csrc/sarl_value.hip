@@ -236,11 +236,13 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
 
     // global state = mean over humans (sarl.py:41); its contribution to attention layer 0 is the same for
     // every human of the pair, so it becomes the accumulator init of that layer
-    const float fn = (float)ne;
+    // (one correctly rounded reciprocal + 28 multiplies instead of 28 IEEE divisions of ~11 instructions each: vector
+    //  instructions are paid beside float32 MFMAs; the mean moves by <= 1 ulp, far inside the 1e-5 bar)
+    const float inv_n = 1.0f / (float)ne;
 #pragma unroll
     for (int t = 0; t < T100; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gsum[t][r] = gsum[t][r] / fn;
+        for (int r = 0; r < 4; ++r) gsum[t][r] = gsum[t][r] * inv_n;
     f32x4 gat[T100];
     dense_staged<T100, T100, false, false, 1>(gsum, nullptr, gat, p.f.w_atg, p.f.b_ata, S, lane);
     SARL_PHASE(5);                      // reward ladder, mean, global half of attention.0
@@ -294,10 +296,11 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
     f32x4 jin[T56];
     {
         // weights = exp(s) (s != 0) / sum (sarl.py:52-53): normalise the accumulated hidden activations, then mlp2.2
+        const float inv_d = 1.0f / denom;            // 0 / 0 stays NaN (0 * inf), as in the reference's softmax
 #pragma unroll
         for (int t = 0; t < T100; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) racc[t][r] = racc[t][r] / denom;
+            for (int r = 0; r < 4; ++r) racc[t][r] = racc[t][r] * inv_d;
         f32x4 pooled[T50];
         dense_staged<T100, T50, false, false, 1>(racc, nullptr, pooled, p.f.w_m2b, p.f.b_m2b, S, lane);
 #pragma unroll

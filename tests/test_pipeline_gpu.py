@@ -131,7 +131,8 @@ def test_world_kernels_follow_the_module_through_training_steps(kind):
     world.eval()
     v1 = fast(env.hpos).clone()                     # no refresh()
     want1 = slow(env.hpos)
-    assert float((v1 - want1).abs().max()) <= 1e-5
+    # (AttentionWorld has no output non-linearity: after a large step its outputs are in the hundreds -- relative bar)
+    assert float((v1 - want1).abs().max()) <= 1e-5 * max(1.0, float(want1.abs().max()))
     assert float((v1 - v0).abs().max()) > 1e-3, "the step must have changed the predictions"
     # load_state_dict replaces the values in place
     torch.manual_seed(9)

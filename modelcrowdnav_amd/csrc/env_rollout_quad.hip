@@ -192,6 +192,8 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
     double o_rew = 0, o_dmin = 0;             // the step record of the latest step (stored once, after the loop)
     int o_dn = 0, o_inf = 0, o_hh = 0;
     double hax = 0, hay = 0;
+    // 1 / timeHorizon and 1 / timeStep once per launch, opaque (quad_common.hpp: quad_orca_velocity)
+    const float inv_th = in_vgpr(1.0f / c.orca_time_horizon), inv_ts = in_vgpr(1.0f / (float)c.time_step);
     STAMP(1);
 
     for (int t = 0; t < T; ++t) {
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
             if (cand_r) { cvx = (float)rvel.x; cvy = (float)rvel.y; }
             float rx, ry;
             quad_orca_velocity(c, lane, k, cand_h || cand_r, pos, vel, goal, rad, vpref,
-                               make_float4((float)cpos.x, (float)cpos.y, cvx, cvy), crd, dt, rx, ry);
+                               make_float4((float)cpos.x, (float)cpos.y, cvx, cvy), crd, inv_th, inv_ts, rx, ry);
             hax = (double)rx; hay = (double)ry;
         }
 

@@ -179,8 +179,10 @@ __device__ __forceinline__ void env_step_body(const StepParams &p)
                 // the lower index), parks (u, dir) in the LDS rows the run-time-N kernel uses for its lines, and every
                 // lane then reads its NT-1 half-planes back with the owner's sign.  Halves the dominant VALU block.
                 constexpr int FW = NT / 2;                        // forward pairs a lane may own
-                const float inv_th = 1.0f / c.orca_time_horizon;
-                const float inv_ts = 1.0f / (float)dt;
+                // (opaque, hoistable: the compiler would otherwise fold `apart ? 1 / a : 1 / b` in the half-plane
+                //  construction into one IEEE division after the select, on every step's critical path)
+                float inv_th = 1.0f / c.orca_time_horizon, inv_ts = 1.0f / (float)dt;
+                asm("" : "+v"(inv_th), "+v"(inv_ts));
                 if constexpr (NT >= 2) {
 #pragma unroll
                     for (int s_ = 1; s_ <= FW; ++s_) {

@@ -109,8 +109,11 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64) void env_step_quad_kernel(const S
     double hax = 0, hay = 0;
     if (do_orca) {
     float rx, ry;
+    // (opaque reciprocals: the compiler would fold `apart ? 1 / a : 1 / b` into one IEEE division after the select)
+    float inv_th = 1.0f / c.orca_time_horizon, inv_ts = 1.0f / (float)dt;
+    asm("" : "+v"(inv_th), "+v"(inv_ts));
     quad_orca_velocity(c, lane, k, cand_h || cand_r, pos, vel, goal, rad, vpref,
-                       make_float4((float)cpos.x, (float)cpos.y, (float)cvel.x, (float)cvel.y), crd, dt, rx, ry);
+                       make_float4((float)cpos.x, (float)cpos.y, (float)cvel.x, (float)cvel.y), crd, inv_th, inv_ts, rx, ry);
     hax = (double)rx; hay = (double)ry;
     }
 

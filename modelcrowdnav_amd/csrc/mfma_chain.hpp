@@ -348,4 +348,181 @@ __device__ __forceinline__ void dense_staged(const f32x4 (&in)[KT], const f32x4 
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// dense_flow: the staged layer as ONE continuous weight stream across layers (round 4).
+// dense_staged starts every layer with "DMA chunk 0, wait, barrier": an L2 -> LDS round trip (~1 500 cycles) during
+// which the wavefront does nothing, 40 times per 16-pair tile of the SARL look-ahead.  Here a layer also issues the DMA
+// of the FIRST chunk of the layer that follows it (NextChunk) -- at the first group of its own last chunk, into the
+// stage buffer that chunk does not use -- and the barrier before its last group (which every layer has anyway) is
+// what makes that chunk visible.  A layer therefore begins reading at once; per tile there is one barrier per staged
+// chunk and no other synchronisation.  The double buffer alternates across layers: WeightFlow.parity is which buffer
+// holds chunk 0 of the layer about to run (chunk c of it sits in buffer (parity + c) & 1).
+struct NextChunk {
+    const float4 *w; int n_w;       // fragments of the following layer's chunk 0 (n_w float4; 0 = nothing follows)
+    const float4 *b; int n_b;       // its bias fragments (n_b float4; 0 = accumulators start from `init`)
+    int b_at;                       // float4 offset of the bias fragments inside the stage buffer
+};
+// Output tiles per staged chunk of a dense_flow layer: as chunk_tiles(), except that a one-k-tile layer (the 13-wide
+// input layer: 10 output tiles x 1 KiB) is ONE chunk -- three barriers for 40 MFMAs were most of that layer's time.
+// The bias fragments sit right behind the chunk's weight fragments (every layer's chunk + biases fits the 32-KiB
+// stage), so the chunk size is not tied to a fixed bias region.
+__host__ __device__ constexpr int flow_chunk_tiles(int KT) { return KT <= 2 ? kChunkScale * 12 : chunk_tiles(KT); }
+template <int KT, int NT, bool HAS_INIT>
+__device__ __forceinline__ NextChunk first_chunk(const float4 *wf, const float4 *bf)
+{
+    constexpr int CH = flow_chunk_tiles(KT) * KT * 64, TOTAL = NT * KT * 64, BCH = flow_chunk_tiles(KT) * 64;
+    static_assert(CH + (HAS_INIT ? 0 : BCH) <= kStageFloat4 + kStageBias, "chunk + biases do not fit the LDS stage");
+    return NextChunk{wf, CH < TOTAL ? CH : TOTAL, HAS_INIT ? nullptr : bf, HAS_INIT ? 0 : (BCH < NT * 64 ? BCH : NT * 64), CH};
+}
+struct WeightFlow {
+    float4 *buf;      // LDS, 2 * (kStageFloat4 + kStageBias) float4
+    int tid;          // threadIdx.x
+    int parity;       // wave-uniform: buffer of the next layer's chunk 0
+};
+constexpr int kStageBuf = kStageFloat4 + kStageBias;
+
+// DMA of a layer's chunk 0 into stage buffer `b` (0 / 1, run-time); every thread of the workgroup calls it.
+__device__ __forceinline__ void flow_stage_first(const WeightFlow &F, const NextChunk &d, int b)
+{
+    int tid_ = F.tid;
+    asm volatile("" : "+v"(tid_));
+    const int wave_base = tid_ & ~63;
+    float4 *dst = F.buf + b * kStageBuf;
+#pragma unroll
+    for (int k = 0; k < kStageFloat4 / kStageThreads; ++k) {
+        if (k * kStageThreads < d.n_w) {                                   // wave-uniform
+            int i = tid_ + k * kStageThreads;
+            i = i < d.n_w - 1 ? i : d.n_w - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(d.w + i),
+                                             (__attribute__((address_space(3))) void *)(dst + k * kStageThreads + wave_base),
+                                             16, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {                                          // up to 12 bias tiles
+        if (k * kStageThreads < d.n_b) {
+            int i = tid_ + k * kStageThreads;
+            i = i < d.n_b - 1 ? i : d.n_b - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(d.b + i),
+                                             (__attribute__((address_space(3))) void *)(dst + d.b_at + k * kStageThreads + wave_base),
+                                             16, 0, 0);
+        }
+    }
+}
+
+// Precondition: chunk 0 of this layer has been requested into buffer F.parity AND a workgroup barrier (with vmcnt(0))
+// has been passed since -- the previous layer's last barrier, or the caller's own at the very beginning.
+template <int KT, int NT, bool RELU, bool HAS_INIT, int LAST = 4, int LAST2 = 4>
+__device__ __forceinline__ void dense_flow(const f32x4 (&in)[KT], const f32x4 *init, f32x4 (&out)[NT],
+                                           const float4 *__restrict__ wf, const float4 *__restrict__ bf,
+                                           WeightFlow &F, int lane, const NextChunk &next)
+{
+    constexpr int kChunkTiles = flow_chunk_tiles(KT);
+    constexpr int CH = kChunkTiles * KT * 64;
+    constexpr int TOTAL = NT * KT * 64;
+    constexpr int NCH = (NT + kChunkTiles - 1) / kChunkTiles;
+    constexpr int PER = (CH + kStageThreads - 1) / kStageThreads;
+    constexpr int BCH = kChunkTiles * 64;
+    constexpr int BPER = (BCH + kStageThreads - 1) / kStageThreads;
+    static_assert(CH + (HAS_INIT ? 0 : BCH) <= kStageFloat4 + kStageBias, "chunk + biases do not fit the LDS stage");
+    static_assert(CH % kStageThreads == 0 || NCH == 1, "a staged chunk is a whole number of DMA rounds");
+    float4 *const bufp[2] = {F.buf + F.parity * kStageBuf, F.buf + (F.parity ^ 1) * kStageBuf};
+    auto stage = [&](int c) {                             // chunk c >= 1 of THIS layer -> buffer (parity + c) & 1
+        int tid_ = F.tid;
+        asm volatile("" : "+v"(tid_));
+        const int wave_base = tid_ & ~63;
+        float4 *dst = bufp[c & 1];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            int i = c * CH + tid_ + k * kStageThreads;
+            if ((c + 1) * CH > TOTAL) i = i < TOTAL - 1 ? i : TOTAL - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wf + i),
+                                             (__attribute__((address_space(3))) void *)(dst + k * kStageThreads + wave_base),
+                                             16, 0, 0);
+        }
+        if (!HAS_INIT) {
+#pragma unroll
+            for (int k = 0; k < BPER; ++k) {
+                int i = c * BCH + tid_ + k * kStageThreads;
+                i = i < NT * 64 - 1 ? i : NT * 64 - 1;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bf + i),
+                                                 (__attribute__((address_space(3))) void *)(dst + CH + k * kStageThreads + wave_base),
+                                                 16, 0, 0);
+            }
+        }
+    };
+    constexpr int PAIRS = (kChunkTiles + 1) / 2;
+    constexpr int NP = (NT + 1) / 2;
+    constexpr int NG = NP * KT;
+    float4 ra[2], rb[2], ba = make_float4(0, 0, 0, 0), bb = make_float4(0, 0, 0, 0);
+    rb[0] = rb[1] = make_float4(0, 0, 0, 0);
+    auto issue = [&](int g) {
+        const int pr = g / KT, t = g - pr * KT;
+        const int c = pr / PAIRS, h2 = 2 * (pr - c * PAIRS), n = 2 * pr;
+        const float4 *wc = bufp[c & 1];
+        const float4 *w = wc + h2 * KT * 64;
+        ra[g & 1] = w[t * 64 + lane];
+        if (n + 1 < NT) rb[g & 1] = w[(KT + t) * 64 + lane];
+        if (t == 0 && !HAS_INIT) {
+            const float4 *bc = wc + CH;
+            ba = bc[h2 * 64 + lane];
+            if (n + 1 < NT) bb = bc[(h2 + 1) * 64 + lane];
+        }
+    };
+    issue(0);
+    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int pr = g / KT, t = g - pr * KT;
+        const int c = pr / PAIRS, n = 2 * pr;
+        const bool two = (n + 1 < NT);
+        const bool chunk_first = (t == 0) && (pr == c * PAIRS);
+        const bool chunk_last = (t == KT - 1) && ((pr == c * PAIRS + PAIRS - 1) || (pr == NP - 1));
+        // a one-group chunk (not used by any layer today) would have to request the following data before its barrier
+        if (chunk_first && chunk_last) {
+            if (c + 1 < NCH) stage(c + 1);
+            else if (next.n_w > 0) flow_stage_first(F, next, (F.parity + NCH) & 1);
+        }
+        if (chunk_last) __syncthreads();      // reads of chunk c all issued and back; the DMAs requested so far have landed
+        if (t == 0) {
+            if (HAS_INIT) { a0 = init[n]; if (two) a1 = init[n + 1]; }
+            else { a0 = (f32x4){ba.x, ba.y, ba.z, ba.w}; if (two) a1 = (f32x4){bb.x, bb.y, bb.z, bb.w}; }
+        }
+        const float4 w0 = ra[g & 1], w1 = rb[g & 1];
+        const int steps = (t == KT - 1) ? LAST : ((t == KT - 2) ? LAST2 : 4);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, in[t][0], a0, 0, 0, 0);
+        if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, in[t][0], a1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < NG) issue(g + 1);
+        if (chunk_first && !chunk_last) {
+            if (c + 1 < NCH) stage(c + 1);                                    // next chunk of this layer, other buffer
+            else if (next.n_w > 0) flow_stage_first(F, next, (F.parity + NCH) & 1);   // chunk 0 of the layer that follows
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (steps > 1) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, in[t][1], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, in[t][1], a1, 0, 0, 0);
+        }
+        if (steps > 2) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, in[t][2], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, in[t][2], a1, 0, 0, 0);
+        }
+        if (steps > 3) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, in[t][3], a0, 0, 0, 0);
+            if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, in[t][3], a1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t == KT - 1) {
+            if (RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a0[r] = relu_f32(a0[r]); a1[r] = relu_f32(a1[r]); }
+            }
+            out[n] = a0;
+            if (two) out[n + 1] = a1;
+        }
+    }
+    F.parity = (F.parity + NCH) & 1;
+}
+
 }  // namespace mcn

@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "orca_device.hpp"
+#include "fast_f32.hpp"
 
 namespace mcn {
 
@@ -66,8 +67,9 @@ __device__ __forceinline__ float4 orca_line_merged(float px, float py, float vx,
 // Returns (u.x, u.y, dir.x, dir.y): the half-plane is point = v + u / 2, direction = dir.
 // Every operation is odd-symmetric under swapping the two agents (relative position and velocity change sign, the
 // radius sum does not), so the pair's other half-plane is exactly (-u, -dir): env_step.hip builds each pair once.
+// `used`: lanes whose half-plane is consumed (an empty candidate slot's operands must not force the IEEE path).
 __device__ __forceinline__ float4 orca_u_dir(float px, float py, float vx, float vy, float radius, float4 o,
-                                             float orad, float inv_th, float inv_ts)
+                                             float orad, float inv_th, float inv_ts, bool used = true)
 {
     const float rpx = o.x - px, rpy = o.y - py;
     const float rvx = vx - o.z, rvy = vy - o.w;
@@ -80,15 +82,30 @@ __device__ __forceinline__ float4 orca_u_dir(float px, float py, float vx, float
     const float wl_sq = dot2(wx, wy, wx, wy);
     const float dp1 = dot2(wx, wy, rpx, rpy);
     const bool circle = !apart | ((dp1 < 0.0f) & (dp1 * dp1 > cr_sq * wl_sq));
+    // The block's two roots and two reciprocals behind ONE wave-uniform range guard (fast_f32.hpp): |w|^2 and the
+    // squared leg inside sqrt5's range (their roots are then inside rcp3's), dist^2 -- at least the squared leg, so
+    // normal -- below 2^126.  Same bits as the IEEE expansions either way.
+    const float leg_sq = dist_sq - cr_sq;
+    float wl, iw, leg, id;
+#if MCN_FAST_F32
+    // (a lane that takes the cut-off circle -- every colliding pair does -- only needs |w|, one that takes a leg only
+    //  the leg and dist^2: a negative squared leg of an overlapping pair must not send the wavefront down the slow path)
+    // (lane masks combined on the scalar unit: as booleans the compiler materialises them in vector registers)
+    const unsigned long long m_circle = __builtin_amdgcn_ballot_w64(circle), m_used = __builtin_amdgcn_ballot_w64(used);
+    const unsigned long long m_w = __builtin_amdgcn_ballot_w64(sqrt5_ok(wl_sq));
+    const unsigned long long m_l = __builtin_amdgcn_ballot_w64(sqrt5_ok(leg_sq)) & __builtin_amdgcn_ballot_w64(dist_sq < 0x1p126f);
+    if ((m_used & ~((m_circle & m_w) | (~m_circle & m_l))) == 0) {
+        wl = sqrt5(wl_sq); iw = rcp3(wl); leg = sqrt5(leg_sq); id = rcp3(dist_sq);
+    } else
+#endif
+    {
+        wl = sqrtf(wl_sq); iw = 1.0f / wl; leg = sqrtf(leg_sq); id = 1.0f / dist_sq;
+    }
     // cut-off circle
-    const float wl = sqrtf(wl_sq);
-    const float iw = 1.0f / wl;
     const float uwx = wx * iw, uwy = wy * iw;
     const float sc = cr * inv - wl;
     const float cux = sc * uwx, cuy = sc * uwy;
     // legs
-    const float leg = sqrtf(dist_sq - cr_sq);
-    const float id = 1.0f / dist_sq;
     const bool left = det2(rpx, rpy, wx, wy) > 0.0f;
     const float lx = (rpx * leg - rpy * cr) * id, ly = (rpx * cr + rpy * leg) * id;
     const float rx = -((rpx * leg + rpy * cr) * id), ry = -((-rpx * cr + rpy * leg) * id);
@@ -101,9 +118,9 @@ __device__ __forceinline__ float4 orca_u_dir(float px, float py, float vx, float
 }
 
 __device__ __forceinline__ float4 orca_line_select(float px, float py, float vx, float vy, float radius, float4 o,
-                                                   float orad, float inv_th, float inv_ts)
+                                                   float orad, float inv_th, float inv_ts, bool used = true)
 {
-    const float4 ud = orca_u_dir(px, py, vx, vy, radius, o, orad, inv_th, inv_ts);
+    const float4 ud = orca_u_dir(px, py, vx, vy, radius, o, orad, inv_th, inv_ts, used);
     return make_float4(vx + 0.5f * ud.x, vy + 0.5f * ud.y, ud.z, ud.w);
 }
 
@@ -116,7 +133,7 @@ __device__ __forceinline__ bool lp1_s(const float4 (&L)[NL], float radius, float
     const float dp = dot2(ln.x, ln.y, ln.z, ln.w);
     const float disc = dp * dp + radius * radius - dot2(ln.x, ln.y, ln.x, ln.y);
     if (disc < 0.0f) return false;
-    const float sq = sqrtf(disc);
+    const float sq = sqrt_f32(disc);
     float tl = -dp - sq;
     float tr = -dp + sq;
     bool ok = true;
@@ -196,7 +213,7 @@ struct Lp3Step {
                             qx = li.x + sc * li.z; qy = li.y + sc * li.w;
                         }
                         const float ddx = lj.z - li.z, ddy = lj.w - li.w;
-                        const float inv = 1.0f / sqrtf(dot2(ddx, ddy, ddx, ddy));
+                        const float inv = rcp_sqrt_f32(dot2(ddx, ddy, ddx, ddy));
                         const float4 q = make_float4(qx, qy, ddx * inv, ddy * inv);
                         // compact the kept lines to the front (m is the running count): static slots via selects
 #pragma unroll
@@ -271,7 +288,7 @@ __device__ __forceinline__ void orca_solve_static(float4 (&cpv)[NC > 0 ? NC : 1]
     // 2-D LP: start from the preferred velocity clipped to the speed disc
     float rx, ry;
     if (dot2(prefx, prefy, prefx, prefy) > max_speed * max_speed) {
-        const float inv = 1.0f / sqrtf(dot2(prefx, prefy, prefx, prefy));
+        const float inv = rcp_sqrt_f32(dot2(prefx, prefy, prefx, prefy));
         rx = max_speed * (prefx * inv); ry = max_speed * (prefy * inv);
     } else {
         rx = prefx; ry = prefy;
@@ -331,7 +348,7 @@ __device__ __forceinline__ void orca_sort_lp2(float4 (&Lnat)[NC > 0 ? NC : 1], f
     nl = nin < max_neighbors ? nin : max_neighbors;
     if (nl > NL) nl = NL;
     if (dot2(prefx, prefy, prefx, prefy) > max_speed * max_speed) {
-        const float inv = 1.0f / sqrtf(dot2(prefx, prefy, prefx, prefy));
+        const float inv = rcp_sqrt_f32(dot2(prefx, prefy, prefx, prefy));
         rx = max_speed * (prefx * inv); ry = max_speed * (prefy * inv);
     } else {
         rx = prefx; ry = prefy;

@@ -49,7 +49,7 @@ __device__ __forceinline__ bool lp1_rt(const float4 (&L)[4], int no, float radiu
     const float dp = dot2(ln.x, ln.y, ln.z, ln.w);
     const float disc = dp * dp + radius * radius - dot2(ln.x, ln.y, ln.x, ln.y);
     bool ok = !(disc < 0.0f);
-    const float sq = sqrtf(disc);
+    const float sq = sqrt_f32(disc, ok);
     float tl = -dp - sq;
     float tr = -dp + sq;
     // straight-line: every lane runs all three steps and masks them with selects (a lone wavefront per SIMD pays
@@ -97,7 +97,7 @@ __device__ __forceinline__ bool lp3_candidate_quad(const float4 (&L)[4], int i, 
     const int kept = ((k < i) & !(par & (dot2(li.z, li.w, lj.z, lj.w) > 0.0f))) ? 1 : 0;
     const float sc = det2(lj.z, lj.w, li.x - lj.x, li.y - lj.y) / dt;
     const float ddx = lj.z - li.z, ddy = lj.w - li.w;
-    const float inv = 1.0f / sqrtf(dot2(ddx, ddy, ddx, ddy));
+    const float inv = rcp_sqrt_f32(dot2(ddx, ddy, ddx, ddy), kept != 0);   // dropped / self projections: unused
     const float4 q = make_float4(par ? 0.5f * (li.x + lj.x) : li.x + sc * li.z,
                                  par ? 0.5f * (li.y + lj.y) : li.y + sc * li.w, ddx * inv, ddy * inv);
     const float4 P0 = qb4<0>(q), P1 = qb4<1>(q), P2 = qb4<2>(q);
@@ -108,7 +108,7 @@ __device__ __forceinline__ bool lp3_candidate_quad(const float4 (&L)[4], int i, 
     const float dp = dot2(q.x, q.y, q.z, q.w);
     const float disc = dp * dp + radius * radius - dot2(q.x, q.y, q.x, q.y);
     bool ok = !(disc < 0.0f);
-    const float sq = sqrtf(disc);
+    const float sq = sqrt_f32(disc, ok & (kept != 0));
     float tl = -dp - sq;
     float tr = -dp + sq;
 #pragma unroll
@@ -146,9 +146,12 @@ __device__ __forceinline__ bool lp3_candidate_quad(const float4 (&L)[4], int i, 
 // ORCA velocity of the human owning this quad.  Lane k holds candidate neighbour k: `o` = its (px, py, vx, vy) in
 // float32, `crd` its radius, `cand_valid` whether the slot is populated.  The result is identical on the four
 // lanes of the quad (layout: lane = 4 * human + k).
+// inv_th / inv_ts = 1 / timeHorizon, 1 / timeStep: computed by the caller once per launch and handed over as opaque
+// values -- left to itself the compiler rewrites `apart ? 1 / a : 1 / b` into `1 / (apart ? a : b)`, i.e. one IEEE
+// division (11 instructions) on the critical path of EVERY step instead of two before the step loop.
 __device__ __forceinline__ void quad_orca_velocity(const mcn_env_cfg &c, int lane, int k, bool cand_valid,
                                                    double2 pos, double2 vel, double2 goal, double rad, double vpref,
-                                                   float4 o, double crd, double dt, float &rx, float &ry)
+                                                   float4 o, double crd, float inv_th, float inv_ts, float &rx, float &ry)
 {
     const float fpx = (float)pos.x, fpy = (float)pos.y, fvx = (float)vel.x, fvy = (float)vel.y;
     const float frad = (float)(rad + 0.01 + c.orca_safety_space);
@@ -169,9 +172,7 @@ __device__ __forceinline__ void quad_orca_velocity(const mcn_env_cfg &c, int lan
     const int rank_out = nin + (((0 < k) & !i0) ? 1 : 0) + (((1 < k) & !i1) ? 1 : 0) + (((2 < k) & !i2) ? 1 : 0);
     const int rank = in ? rank_in : rank_out;
     int nl = nin < c.orca_max_neighbors ? nin : c.orca_max_neighbors;
-    const float inv_th = 1.0f / c.orca_time_horizon;
-    const float inv_ts = 1.0f / (float)dt;
-    const float4 mine = orca_line_select(fpx, fpy, fvx, fvy, frad, o, orad, inv_th, inv_ts);
+    const float4 mine = orca_line_select(fpx, fpy, fvx, fvy, frad, o, orad, inv_th, inv_ts, in != 0);
     // route my half-plane to lane `rank` of the quad, then share all four
     const int dst = ((lane & ~3) | rank) << 2;
     float4 srt;
@@ -186,8 +187,8 @@ __device__ __forceinline__ void quad_orca_velocity(const mcn_env_cfg &c, int lan
     const int okm = lp1_rt<false>(L, k, ms, prefx, prefy, cx, cy) ? 1 : 0;
     {
         const float pp = dot2(prefx, prefy, prefx, prefy);
-        const float inv = 1.0f / sqrtf(pp);
         const bool clip = pp > ms * ms;
+        const float inv = rcp_sqrt_f32(pp, clip);
         rx = clip ? ms * (prefx * inv) : prefx;
         ry = clip ? ms * (prefy * inv) : prefy;
     }

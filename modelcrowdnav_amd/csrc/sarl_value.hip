@@ -38,6 +38,7 @@
 #include <stdint.h>
 #include "../../include/mcn.h"
 #include "mfma_chain.hpp"
+#include "fast_f32.hpp"
 
 namespace mcn {
 
@@ -112,11 +113,38 @@ int read_sarl_phases(void *dst, size_t bytes, int reset)
 
 constexpr int kSarlWaves = kStageThreads / 64;     // 8 wavefronts share one LDS weight stage (2 per SIMD)
 
+// MCN_SARL_FLOW = 1 (default): the layers of a tile (and of the next tile) form ONE weight stream -- each layer requests
+// the first staged chunk of the layer that follows it (mfma_chain.hpp: dense_flow); 0: every layer starts with its own
+// DMA + wait + barrier (dense_staged), the form of rounds 1-3, kept for A/B runs.
+#ifndef MCN_SARL_FLOW
+#define MCN_SARL_FLOW 1
+#endif
+#if MCN_SARL_FLOW
+#define SARL_LAYER(KT, NT, RELU, INIT, L1, L2, in, init, out, w, b, next) \
+    dense_flow<KT, NT, RELU, INIT, L1, L2>(in, init, out, w, b, F, lane, next)
+#else
+#define SARL_LAYER(KT, NT, RELU, INIT, L1, L2, in, init, out, w, b, next) \
+    dense_staged<KT, NT, RELU, INIT, L1, L2>(in, init, out, w, b, S, lane)
+#endif
+
 __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl_value_kernel(const SarlParams p)
 {
     __shared__ float4 s_stage[2 * (kStageFloat4 + kStageBias)];
     const long npairs = (long)p.E * p.A;
     const int N = p.N;
+#if MCN_SARL_FLOW
+    // chunk 0 of every layer, as the layer before it requests it
+    const NextChunk d_m1a = first_chunk<T13, T150, false>(p.f.w_m1a, p.f.b_m1a), d_m1b = first_chunk<T150, T100, false>(p.f.w_m1b, p.f.b_m1b);
+    const NextChunk d_atg = first_chunk<T100, T100, false>(p.f.w_atg, p.f.b_ata), d_ata = first_chunk<T100, T100, true>(p.f.w_ata, nullptr);
+    const NextChunk d_atb = first_chunk<T100, T100, false>(p.f.w_atb, p.f.b_atb), d_atc = first_chunk<T100, T1, false>(p.f.w_atc, p.f.b_atc);
+    const NextChunk d_m2a = first_chunk<T100, T100, false>(p.f.w_m2a, p.f.b_m2a), d_m2b = first_chunk<T100, T50, false>(p.f.w_m2b, p.f.b_m2b);
+    const NextChunk d_m3a = first_chunk<T56, T150, false>(p.f.w_m3a, p.f.b_m3a), d_m3b = first_chunk<T150, T100, false>(p.f.w_m3b, p.f.b_m3b);
+    const NextChunk d_m3c = first_chunk<T100, T100, false>(p.f.w_m3c, p.f.b_m3c), d_m3d = first_chunk<T100, T1, false>(p.f.w_m3d, p.f.b_m3d);
+    const NextChunk d_none = {nullptr, 0, nullptr, 0};
+    WeightFlow F{s_stage, (int)threadIdx.x, 0};
+    if ((long)blockIdx.x < p.ngroups) flow_stage_first(F, d_m1a, 0);         // the very first layer of this workgroup
+    __syncthreads();
+#endif
     // every wavefront of the workgroup runs the same number of passes (the weight-staging barriers are collective)
 #pragma unroll 1
   for (long grp = blockIdx.x; grp < p.ngroups; grp += gridDim.x) {
@@ -182,6 +210,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
         int tid_i = tid;
         asm volatile("" : "+v"(tid_i));
         const WeightStage S{s_stage, tid_i};
+        (void)S;
         const long ha = (long)e * N + i;
         const double2 hp = reinterpret_cast<const double2 *>(p.hpos)[ha];
         const double2 hv = reinterpret_cast<const double2 *>(p.hvel)[ha];
@@ -204,7 +233,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
         feat[8] = hvx * cr + hvy * sr;
         feat[9] = hvy * cr - hvx * sr;
         feat[10] = hrad;
-        { const float ax_ = spx - hx, ay_ = spy - hy; feat[11] = sqrtf(ax_ * ax_ + ay_ * ay_); }
+        { const float ax_ = spx - hx, ay_ = spy - hy; feat[11] = sqrt_f32(ax_ * ax_ + ay_ * ay_); }   // == sqrtf (fast_f32.hpp)
         feat[12] = srad + hrad;
         feat[13] = feat[14] = feat[15] = 0.0f;
         f32x4 x[T13];
@@ -213,10 +242,10 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
             x[0][r] = q == 0 ? feat[r] : (q == 1 ? feat[4 + r] : (q == 2 ? feat[8 + r] : feat[12 + r]));
         SARL_PHASE(1);                  // per human: state loads, float64 distance, rotated features
         f32x4 h1[T150];
-        dense_staged<T13, T150, true, false>(x, nullptr, h1, p.f.w_m1a, p.f.b_m1a, S, lane);
+        SARL_LAYER(T13, T150, true, false, 4, 4, x, nullptr, h1, p.f.w_m1a, p.f.b_m1a, d_m1b);
         SARL_PHASE(2);                  // mlp1.0
         f32x4 h2[T100];
-        dense_staged<T150, T100, true, false, 2>(h1, nullptr, h2, p.f.w_m1b, p.f.b_m1b, S, lane);
+        SARL_LAYER(T150, T100, true, false, 2, 4, h1, nullptr, h2, p.f.w_m1b, p.f.b_m1b, (i + 1 < N ? d_m1a : d_atg));
         SARL_PHASE(3);                  // mlp1.2
 #pragma unroll
         for (int t = 0; t < T100; ++t) {
@@ -244,7 +273,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
 #pragma unroll
         for (int r = 0; r < 4; ++r) gsum[t][r] = gsum[t][r] * inv_n;
     f32x4 gat[T100];
-    dense_staged<T100, T100, false, false, 1>(gsum, nullptr, gat, p.f.w_atg, p.f.b_ata, S, lane);
+    SARL_LAYER(T100, T100, false, false, 1, 4, gsum, nullptr, gat, p.f.w_atg, p.f.b_ata, d_ata);
     SARL_PHASE(5);                      // reward ladder, mean, global half of attention.0
 
     // ---- pass 2: attention score, mlp2, pooling ----
@@ -260,6 +289,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
         int tid_i = tid;
         asm volatile("" : "+v"(tid_i));
         const WeightStage S{s_stage, tid_i};
+        (void)S;
         f32x4 h2[T100];
 #pragma unroll
         for (int t = 0; t < T100; ++t) {
@@ -268,13 +298,13 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
         }
         SARL_PHASE(6);                  // workspace load
         f32x4 a1[T100];
-        dense_staged<T100, T100, true, true, 1>(h2, gat, a1, p.f.w_ata, nullptr, S, lane);
+        SARL_LAYER(T100, T100, true, true, 1, 4, h2, gat, a1, p.f.w_ata, nullptr, d_atb);
         SARL_PHASE(7);                  // attention.0
         f32x4 a2[T100];
-        dense_staged<T100, T100, true, false, 1>(a1, nullptr, a2, p.f.w_atb, p.f.b_atb, S, lane);
+        SARL_LAYER(T100, T100, true, false, 1, 4, a1, nullptr, a2, p.f.w_atb, p.f.b_atb, d_atc);
         SARL_PHASE(8);                  // attention.2
         f32x4 sc[T1];
-        dense_staged<T100, T1, false, false, 1>(a2, nullptr, sc, p.f.w_atc, p.f.b_atc, S, lane);
+        SARL_LAYER(T100, T1, false, false, 1, 4, a2, nullptr, sc, p.f.w_atc, p.f.b_atc, d_m2a);
         SARL_PHASE(9);                  // attention.4
         // score of pair j sits in lane j (q = 0), register 0; broadcast to the pair's four lanes
         const float s = __shfl(sc[0][0], j);
@@ -283,12 +313,12 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
         denom += es;
         SARL_PHASE(10);                 // exp, attention output
         f32x4 m1[T100];
-        dense_staged<T100, T100, true, false, 1>(h2, nullptr, m1, p.f.w_m2a, p.f.b_m2a, S, lane);
+        SARL_LAYER(T100, T100, true, false, 1, 4, h2, nullptr, m1, p.f.w_m2a, p.f.b_m2a, (i + 1 < N ? d_ata : d_m2b));
         SARL_PHASE(11);                 // mlp2.0
 #pragma unroll
         for (int t = 0; t < T100; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) racc[t][r] = i < ne ? racc[t][r] + es * m1[t][r] : racc[t][r];
+            for (int r = 0; r < 4; ++r) racc[t][r] = i < ne ? __builtin_fmaf(es, m1[t][r], racc[t][r]) : racc[t][r];
         SARL_PHASE(12);                 // weighted accumulation
     }
 
@@ -302,7 +332,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
 #pragma unroll
             for (int r = 0; r < 4; ++r) racc[t][r] = racc[t][r] * inv_d;
         f32x4 pooled[T50];
-        dense_staged<T100, T50, false, false, 1>(racc, nullptr, pooled, p.f.w_m2b, p.f.b_m2b, S, lane);
+        SARL_LAYER(T100, T50, false, false, 1, 4, racc, nullptr, pooled, p.f.w_m2b, p.f.b_m2b, d_m3a);
 #pragma unroll
         for (int t = 0; t < T50; ++t) jin[t] = pooled[t];
     }
@@ -314,13 +344,13 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
     }
     SARL_PHASE(13);                     // normalise, mlp2.2, self tile
     f32x4 v1[T150];
-    dense_staged<T56, T150, true, false, 2, 1>(jin, nullptr, v1, p.f.w_m3a, p.f.b_m3a, S, lane);
+    SARL_LAYER(T56, T150, true, false, 2, 1, jin, nullptr, v1, p.f.w_m3a, p.f.b_m3a, d_m3b);
     f32x4 v2[T100];
-    dense_staged<T150, T100, true, false, 2>(v1, nullptr, v2, p.f.w_m3b, p.f.b_m3b, S, lane);
+    SARL_LAYER(T150, T100, true, false, 2, 4, v1, nullptr, v2, p.f.w_m3b, p.f.b_m3b, d_m3c);
     f32x4 v3[T100];
-    dense_staged<T100, T100, true, false, 1>(v2, nullptr, v3, p.f.w_m3c, p.f.b_m3c, S, lane);
+    SARL_LAYER(T100, T100, true, false, 1, 4, v2, nullptr, v3, p.f.w_m3c, p.f.b_m3c, d_m3d);
     f32x4 vo[T1];
-    dense_staged<T100, T1, false, false, 1>(v3, nullptr, vo, p.f.w_m3d, p.f.b_m3d, S, lane);
+    SARL_LAYER(T100, T1, false, false, 1, 4, v3, nullptr, vo, p.f.w_m3d, p.f.b_m3d, (grp + gridDim.x < p.ngroups ? d_m1a : d_none));
     if (valid && q == 0) {
         // value = reward + gamma^(dt * v_pref) * V   (multi_human_rl.py:52, Python float arithmetic)
         p.values[pair] = reward + p.gamma_pow * (double)vo[0][0];

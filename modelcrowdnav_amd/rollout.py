@@ -70,6 +70,9 @@ class VecExplorer(object):
         self.target_model = None
         self.raw_memory = None                   # list / ReplayMemory-like: rows (ob [N,5], reward, done, info code)
         self.rawob = None                        # list / ReplayMemory-like: (humans [N,4], next velocities [N,2])
+        # True: raw_memory rows carry the reference's value types, (list[ObservableState], reward, done, Info object)
+        # as explorer.py:80-81 pushes them (the drop-in Explorer sets it); False: arrays and integer codes
+        self.raw_rows_as_objects = False
 
     def update_target_model(self, target_model):
         import copy
@@ -80,7 +83,7 @@ class VecExplorer(object):
         return value_targets(states, rewards, dones, infos, imitation_learning, gbar, self.target_model, self.device,
                              return_index=True)
 
-    def _emit_collected(self, cur, ob, rew, done, info, k, rounds, E_total, update_raw_ob, cache_dir):
+    def _emit_collected(self, cur, ob, rew, done, info, dmin, k, rounds, E_total, update_raw_ob, cache_dir):
         """Split the recorded [T,E,...] traces at the dones and hand the k episodes out in the reference's order
         (episode g = round * E + env): raw_memory rows, world-model pairs, SGAN cache files."""
         T, E = done.shape
@@ -96,7 +99,12 @@ class VecExplorer(object):
             t0, t1 = bounds[e][r]
             frames = []
             for t in range(t0, t1 + 1):
-                if self.raw_memory is not None:
+                if self.raw_memory is not None and self.raw_rows_as_objects:
+                    from .envs.utils import info as I
+                    from .envs.utils.state import ObservableState
+                    push(self.raw_memory, ([ObservableState(*[float(x) for x in row]) for row in ob[t, e]],
+                                           float(rew[t, e]), bool(done[t, e]), I.from_code(info[t, e], float(dmin[t, e]))))
+                elif self.raw_memory is not None:
                     push(self.raw_memory, (ob[t, e].copy(), float(rew[t, e]), bool(done[t, e]), int(info[t, e])))
                 if update_raw_ob and (np.abs(ob[t, e, :, 2:4]) > 1e-3).any():        # someone_is_moving
                     push(self.rawob, (torch.from_numpy(cur[t, e]).float(), torch.from_numpy(ob[t, e, :, 2:4].copy()).float()))
@@ -203,7 +211,7 @@ class VecExplorer(object):
             if ws > 1 or action_seq is not None:
                 raise NotImplementedError("data collection runs in one process, one launch per step")
             keep_export, env.export_human_actions = env.export_human_actions, True
-            col_cur, col_ob, col_r, col_d, col_i = [], [], [], [], []
+            col_cur, col_ob, col_r, col_d, col_i, col_m = [], [], [], [], [], []
         t = 0
         if action_seq is not None:
             if update_memory:
@@ -233,6 +241,7 @@ class VecExplorer(object):
                 pos = prev_pos + env.human_act * env.time_step
                 col_ob.append(torch.cat([pos, env.human_act, env.hrad.unsqueeze(2)], 2))
                 col_r.append(env.reward.clone()); col_d.append(env.done.bool()); col_i.append(env.info.clone())
+                col_m.append(env.dmin.clone())
             if update_memory:
                 rec_r.append(env.reward.clone()); rec_d.append(env.done.bool()); rec_i.append(env.info.clone())
             t += 1
@@ -264,7 +273,8 @@ class VecExplorer(object):
             env.export_human_actions = keep_export
             self._emit_collected(torch.stack(col_cur).cpu().numpy(), torch.stack(col_ob).cpu().numpy(),
                                  torch.stack(col_r).cpu().numpy(), torch.stack(col_d).cpu().numpy(),
-                                 torch.stack(col_i).cpu().numpy(), k, rounds, E_total, update_raw_ob, cacheFile)
+                                 torch.stack(col_i).cpu().numpy(), torch.stack(col_m).cpu().numpy(), k, rounds, E_total,
+                                 update_raw_ob, cacheFile)
         env.case_counter[phase] = (first + k) % size if test_case is None else (test_case + 1) % size
         # records in global episode order: episode g = r * E_total + global_env
         # (the envs' "too close" counters ride in the same collective, in the rows of their first episode)

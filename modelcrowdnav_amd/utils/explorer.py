@@ -103,6 +103,7 @@ class Explorer(object):
         vex.policy, vex.robot, vex.gamma = self.robot.policy, self.robot, self.gamma
         vex.memory, vex.target_policy, vex.target_model = self.memory, self.target_policy, self.target_model
         vex.raw_memory, vex.rawob = self.raw_memory, self.rawob
+        vex.raw_rows_as_objects = True            # (list[ObservableState], reward, done, Info object), explorer.py:80-81
         return vex
 
     def run_k_episodes(self, k, phase, update_memory=False, imitation_learning=False, episode=None,

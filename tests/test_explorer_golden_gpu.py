@@ -232,10 +232,16 @@ def test_dropin_explorer_data_collection_matches_reference(tag, stay, cap, golde
     assert ex.last_run_batched
     want = g[tag + "_out"]
     assert tuple(out[1:]) == tuple(want[1:]) and abs(out[0] - want[0]) < 1e-12, (out, want)
-    assert np.array_equal(np.stack([r[0] for r in ex.raw_memory]), g[tag + "_raw_ob"])
+    # rows carry the reference's value types (explorer.py:80-81): list[ObservableState], float, bool, Info object
+    from modelcrowdnav_amd.envs.utils import info as I
+    from modelcrowdnav_amd.envs.utils.state import ObservableState
+    assert all(isinstance(h, ObservableState) for h in ex.raw_memory[0][0]) and isinstance(ex.raw_memory[0][3], I._Outcome)
+    rows_ob = np.array([[[h.px, h.py, h.vx, h.vy, h.radius] for h in r[0]] for r in ex.raw_memory])
+    assert np.array_equal(rows_ob, g[tag + "_raw_ob"])
     assert np.array_equal(np.array([r[1] for r in ex.raw_memory]), g[tag + "_raw_reward"])
     assert np.array_equal(np.array([r[2] for r in ex.raw_memory], np.uint8), g[tag + "_raw_done"])
-    assert np.array_equal(np.array([r[3] for r in ex.raw_memory], np.int32), g[tag + "_raw_info"])
+    assert np.array_equal(np.array([r[3].code for r in ex.raw_memory], np.int32), g[tag + "_raw_info"])
+    assert all(r[3].min_dist < 0.2 for r in ex.raw_memory if isinstance(r[3], I.Danger))
     assert np.array_equal(torch.stack([p[0] for p in ex.rawob]).numpy(), g[tag + "_pairs_cur"])
     assert np.array_equal(torch.stack([p[1] for p in ex.rawob]).numpy(), g[tag + "_pairs_next"])
     for i in range(1, 5):

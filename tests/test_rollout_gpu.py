@@ -597,11 +597,25 @@ def test_reference_driver_sequence_through_dropin():
     assert isinstance(robot.policy, ORCA)
     robot.policy.safety_space = 0
     k = 4
+    explorer.batched = False                  # the sequential E = 1 loop (what k = 1 calls and epsilon-greedy training get)
     avg, sr, cr, tr = explorer.run_k_episodes(k, "test", update_memory=True, imitation_learning=True, print_failure=True)
+    assert not explorer.last_run_batched
     assert abs(sr + cr + tr - 1) < 1e-12 and len(memory) > 0
     assert env.case_counter["test"] == k
     state, value = memory[0]
     assert tuple(state.shape) == (5, 13) and tuple(value.shape) == (1,)
+    # the same call as the drivers make it (k > 1 goes to the batched explorer behind the same class): same statistics,
+    # same memory rows in the same order
+    explorer.batched = True
+    explorer.memory = ReplayMemory(5000)
+    env.case_counter["test"] = 0
+    out_b = explorer.run_k_episodes(k, "test", update_memory=True, imitation_learning=True, print_failure=True)
+    assert explorer.last_run_batched and env.case_counter["test"] == k
+    assert tuple(out_b[1:]) == (sr, cr, tr) and abs(out_b[0] - avg) < 1e-12
+    assert len(explorer.memory) == len(memory)
+    for i in range(len(memory)):
+        np.testing.assert_allclose(explorer.memory[i][0].cpu().numpy(), memory[i][0].cpu().numpy(), rtol=2e-6, atol=2e-6)
+        assert abs(float(explorer.memory[i][1]) - float(memory[i][1])) < 2e-6
     # the same four cases, batched
     venv = H.make_vec_env(k, 5)
     venv.track_human_times = False; venv.export_human_actions = False
@@ -703,6 +717,7 @@ def test_data_collection_side_channels_match_sequential_explorer(stay, tmp_path)
     policy.set_phase("val"); policy.set_device(device); policy.set_env(env)
     robot.policy.safety_space = 0
     ex = Explorer(env, robot, device, None, gamma=0.9)
+    ex.batched = False                       # the sequential E = 1 loop itself (k > 1 would go to the batched explorer)
     ex.raw_memory, ex.rawob = [], []
     out = ex.run_k_episodes(k, "val", stay=stay, update_raw_ob=True, cacheFile=str(seq_dir))
     # ---- batched

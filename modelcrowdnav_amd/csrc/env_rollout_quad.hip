@@ -148,9 +148,10 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
     const mcn_env_cfg &c = p.cfg;
     const mcn_rollout &ro = p.roll;
     const double dt = in_vgpr(c.time_step);
-    const double k_timeout_at = in_vgpr(c.time_limit - 1), k_time_limit = in_vgpr(c.time_limit);
-    const double k_collision = in_vgpr(c.collision_penalty), k_success = in_vgpr(c.success_reward);
-    const double k_discomfort = in_vgpr(c.discomfort_dist), k_factor = in_vgpr(c.discomfort_penalty_factor);
+    // The reward ladder's six constants are NOT kept in registers across the step loop (round 4): pinned in VGPRs four
+    // of them were spilled to scratch at the 168-VGPR cap (9 registers, 40 B per lane: 6 MB of scratch stores per launch
+    // and a scratch reload on every step's ladder); the ladder re-reads them from the kernel-argument segment instead
+    // (two scalar loads from the constant cache, issued by the float64 wavefront, which has slack every step).
     const bool lead = active && r == 0 && do_pair;       // owns the per-env records
     const bool hlead = active && k == 0 && do_orca;      // owns the human's records
     constexpr bool unicycle = UNI;            // compile-time: the holonomic kernel carries no float64 sin / cos code
@@ -186,7 +187,6 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
     const long act_stride = in_vgpr((long)p.E);
     const double *disc_table = in_vgpr(ro.disc_table);
     const int disc_last = in_vgpr(ro.disc_len - 1);
-    const int k_stride = in_vgpr(ro.case_stride), k_pool = in_vgpr(ro.pool_size);
     const bool has_theta = p.st.rtheta != nullptr;
     double2 act_next = *act_ptr;
     double o_rew = 0, o_dmin = 0;             // the step record of the latest step (stored once, after the loop)
@@ -278,6 +278,10 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
                 if (__any(gx * gx + gy * gy < near * near)) DIAG_COUNT(3);
                 if (__any(gx * gx + gy * gy < near * near)) reaching = norm2(gx, gy) < rrad;
             }
+            const KernargPtr kc = kernarg_here();
+            const double k_time_limit = kc->cfg.time_limit, k_timeout_at = k_time_limit - 1;
+            const double k_collision = kc->cfg.collision_penalty, k_success = kc->cfg.success_reward;
+            const double k_discomfort = kc->cfg.discomfort_dist, k_factor = kc->cfg.discomfort_penalty_factor;
             double rew; int inf;
             if (gtime >= k_timeout_at)          { rew = 0; dn = 1; inf = MCN_INFO_TIMEOUT; }
             else if (dmin < 0)                  { rew = k_collision; dn = 1; inf = MCN_INFO_COLLISION; }
@@ -316,6 +320,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, SPLIT ? 3 : 1) void env_rollout_q
                 rs.ep_return = dn ? 0.0 : ret;
                 rs.ep_steps = dn ? 0 : rs.ep_steps + 1;
                 if (do_reset) {
+                    const int k_stride = kc->roll.case_stride, k_pool = kc->roll.pool_size;   // (kernel-argument reads, as the ladder's)
                     int nc = rs.next_case + k_stride;            // both < pool_size (validated on the host)
                     nc = nc >= k_pool ? nc - k_pool : nc;
                     rs.next_case = dn ? nc : rs.next_case;

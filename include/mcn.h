@@ -230,6 +230,22 @@ int mcn_pack_linear(const float *weight, const float *bias, int32_t nout, int32_
                     const int32_t *kmap, int32_t KT, const int32_t *omap, int32_t NT,
                     float *wfrag_out, float *bfrag_out);
 
+/*
+ * mcn_pack_x3 -- HOST helper: regroup float32 weight fragments ([NT][KT][64][4] floats, mcn_pack_linear's wfrag_out)
+ * for the bf16 matrix pipe: every weight as three bfloat16 pieces hi + mid + lo (round-to-nearest-even, exact to
+ * 2^-24), per (output tile, 32-feature input block) three 16-byte rows per lane:
+ * x3_out [NT][ceil(KT / 2)][3][64][8] bfloat16 (mcn_pack_x3_bytes bytes).  With these the look-ahead kernels run
+ * v_mfma_f32_16x16x32_bf16 on six of the nine piece products instead of v_mfma_f32_16x16x4_f32: float32-accurate
+ * (error against float64 as the float32 chain's), ~2.7 x fewer matrix-pipe cycles.
+ */
+int64_t mcn_pack_x3_bytes(int32_t NT, int32_t KT);
+int mcn_pack_x3(const float *wfrag, int32_t NT, int32_t KT, void *x3_out);
+
+/* Device pointers to the bf16x3 fragments of one ValueNetwork (biases stay the float32 fragments of mcn_sarl_net). */
+typedef struct mcn_sarl_x3 {
+    const void *w_m1a, *w_m1b, *w_m2a, *w_m2b, *w_ata, *w_atg, *w_atb, *w_atc, *w_m3a, *w_m3b, *w_m3c, *w_m3d;
+} mcn_sarl_x3;
+
 /* Device pointers to the packed fragments of one ValueNetwork (state_dict keys in comments). */
 typedef struct mcn_sarl_net {
     const float *w_m1a, *b_m1a;   /* mlp1.0        13 -> 150 */
@@ -244,10 +260,13 @@ typedef struct mcn_sarl_net {
     const float *w_m3b, *b_m3b;   /* mlp3.2       150 -> 100 */
     const float *w_m3c, *b_m3c;   /* mlp3.4       100 -> 100 */
     const float *w_m3d, *b_m3d;   /* mlp3.6       100 -> 1   */
+    const mcn_sarl_x3 *x3;        /* HOST pointer or NULL: when set, the layers run on the bf16 pipe from these fragments
+                                   * (ABI 5; the float32 fragments above are still required: biases, and the fallback) */
 } mcn_sarl_net;
 
 /* Bytes of device workspace mcn_sarl_lookahead needs for (E, N, A): one slot per RESIDENT wavefront of the persistent
- * grid (at most 2 048), N x 7 KiB each -- 72 MB at N = 5, whatever E. */
+ * grid (at most 2 048), N x 12 KiB each (the bf16x3 path parks mlp1's output already split; the float32 path uses
+ * 7 KiB of it) -- 123 MB at N = 5, whatever E. */
 int64_t mcn_sarl_workspace_bytes(int32_t E, int32_t N, int32_t A);
 
 /*
@@ -390,7 +409,7 @@ int mcn_attn_world_step(const mcn_attn_world_net *net, const double *hpos, const
  * Dispatch overrides (host, process-wide, not stream-ordered; for tests and tuning).  Every env-step arithmetic
  * exists in several kernel decompositions with bit-identical results; by default the entry points pick one from
  * the batch shape.  -1 = automatic.  The MCN_FORCE_GENERIC / MCN_QUAD_MAX_ENVS / MCN_QUAD_SPLIT /
- * MCN_ROLLOUT_FUSED / MCN_ROLLOUT_SPLIT / MCN_PAIR_STREAM / MCN_STEP_BLOCK / MCN_LP3_DEFER environment variables give the initial values and are read once, at
+ * MCN_ROLLOUT_FUSED / MCN_ROLLOUT_SPLIT / MCN_PAIR_STREAM / MCN_STEP_BLOCK / MCN_LP3_DEFER / MCN_SARL_X3 environment variables give the initial values and are read once, at
  * the first launch; no entry point calls getenv after that.
  */
 typedef struct mcn_tuning {
@@ -405,6 +424,7 @@ typedef struct mcn_tuning {
                               * 2 / 3: wherever it applies, with non-temporal per-human streams forced on / off */
     int32_t lp3_defer;       /* lane-per-human ORCA kernels with mcn_env_out.lp3_queue set: park the 3-D LPs for a second,
                               * dense launch (1) or solve them in the step kernel (0); -1: defer from 8 ORCA neighbours and 16 384 wavefronts */
+    int32_t sarl_x3;         /* SARL look-ahead with mcn_sarl_net.x3 set: bf16x3 layers (1 / -1) or the float32 MFMA layers (0) */
 } mcn_tuning;
 
 /* NULL restores the initial values.  Returns MCN_EINVAL for out-of-range fields.  The settings are one process-wide
@@ -418,15 +438,17 @@ const char *mcn_version(void);
 
 /*
  * ABI guard.  MCN_ABI_VERSION changes whenever a struct of this header changes size or layout or an entry point
- * changes its signature (0.3 grew mcn_tuning by lp3_defer and mcn_env_out by lp3_queue: ABI 4).  A caller built against
+ * changes its signature (0.3 grew mcn_tuning by lp3_defer and mcn_env_out by lp3_queue: ABI 4; 0.4 grew mcn_sarl_net by
+ * x3: ABI 5).  A caller built against
  * another header must not pass structs to this library: compare mcn_abi_version() with the MCN_ABI_VERSION it was
  * compiled with, and (bindings without the header: ctypes, cgo) mcn_sizeof() with the size of its own struct mirrors.
  */
-#define MCN_ABI_VERSION 4
+#define MCN_ABI_VERSION 5
 int32_t mcn_abi_version(void);
 enum { MCN_SIZEOF_ENV_CFG = 0, MCN_SIZEOF_ENV_STATE = 1, MCN_SIZEOF_ENV_OUT = 2, MCN_SIZEOF_ROLLOUT = 3,
        MCN_SIZEOF_TUNING = 4, MCN_SIZEOF_STEP_REC = 5, MCN_SIZEOF_ROLL_REC = 6, MCN_SIZEOF_SARL_NET = 7,
-       MCN_SIZEOF_SGAN_NET = 8, MCN_SIZEOF_SCENARIO_CFG = 9, MCN_SIZEOF_MLP_WORLD_NET = 10, MCN_SIZEOF_ATTN_WORLD_NET = 11 };
+       MCN_SIZEOF_SGAN_NET = 8, MCN_SIZEOF_SCENARIO_CFG = 9, MCN_SIZEOF_MLP_WORLD_NET = 10, MCN_SIZEOF_ATTN_WORLD_NET = 11,
+       MCN_SIZEOF_SARL_X3 = 12 };
 int64_t mcn_sizeof(int32_t which);                 /* sizeof the struct named by MCN_SIZEOF_*; -1 for an unknown id */
 
 /*

@@ -92,7 +92,7 @@ RULE_CIRCLE, RULE_SQUARE = 0, 1
 class Tuning(C.Structure):
     """mcn_tuning: dispatch overrides, -1 = automatic."""
     _fields_ = [(k, _i) for k in ("force_generic", "quad_max_envs", "quad_split", "rollout_fused", "rollout_split",
-                                  "step_block", "diag_noop", "pair_stream", "lp3_defer")]
+                                  "step_block", "diag_noop", "pair_stream", "lp3_defer", "sarl_x3")]
 
 
 class McnError(RuntimeError):
@@ -146,6 +146,8 @@ def _load():
     lib.mcn_sgan_workspace_bytes.restype = C.c_int64
     lib.mcn_sgan_step.argtypes = [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _vp]
     lib.mcn_sgan_step.restype = C.c_int
+    lib.mcn_pack_x3_bytes.argtypes, lib.mcn_pack_x3_bytes.restype = [_i, _i], C.c_int64
+    lib.mcn_pack_x3.argtypes, lib.mcn_pack_x3.restype = [C.POINTER(C.c_float), _i, _i, _vp], C.c_int
     lib.mcn_abi_version.restype = _i
     lib.mcn_sizeof.argtypes, lib.mcn_sizeof.restype = [_i], C.c_int64
     lib.mcn_last_dispatch.restype = C.c_char_p
@@ -153,7 +155,7 @@ def _load():
     return lib
 
 
-ABI_VERSION = 4          # include/mcn.h: MCN_ABI_VERSION this binding's struct mirrors were written against
+ABI_VERSION = 5          # include/mcn.h: MCN_ABI_VERSION this binding's struct mirrors were written against
 
 
 def _check_abi(lib):
@@ -177,7 +179,7 @@ def last_dispatch():
 lib = _load()
 
 # every symbol include/mcn.h declares; tests/test_abi.py checks the .so exports each one
-EXPORTED = ["mcn_version", "mcn_abi_version", "mcn_sizeof", "mcn_last_dispatch", "mcn_set_tuning", "mcn_get_tuning", "mcn_env_step", "mcn_env_lp3_queue_bytes", "mcn_env_rollout", "mcn_scenario_pool", "mcn_orca_batch", "mcn_pack_linear", "mcn_sarl_workspace_bytes",
+EXPORTED = ["mcn_version", "mcn_abi_version", "mcn_sizeof", "mcn_last_dispatch", "mcn_pack_x3", "mcn_pack_x3_bytes", "mcn_set_tuning", "mcn_get_tuning", "mcn_env_step", "mcn_env_lp3_queue_bytes", "mcn_env_rollout", "mcn_scenario_pool", "mcn_orca_batch", "mcn_pack_linear", "mcn_sarl_workspace_bytes",
             "mcn_sarl_lookahead", "mcn_sarl_lookahead_env", "mcn_sarl_predict", "mcn_sgan_workspace_bytes", "mcn_sgan_step", "mcn_mlp_world_step", "mcn_attn_world_workspace_bytes",
             "mcn_attn_world_step"]
 

@@ -65,6 +65,7 @@ static mcn_tuning tuning_from_env()
     t.step_block = env_or("MCN_STEP_BLOCK", -1);
     t.pair_stream = env_or("MCN_PAIR_STREAM", -1);
     t.lp3_defer = env_or("MCN_LP3_DEFER", -1);
+    t.sarl_x3 = env_or("MCN_SARL_X3", -1);
     return t;
 }
 static mcn_tuning tuning()
@@ -72,6 +73,47 @@ static mcn_tuning tuning()
     std::lock_guard<std::mutex> lock(g_tuning_mu);
     if (!g_tuning_init) { g_tuning = tuning_from_env(); g_tuning_init = true; }
     return g_tuning;
+}
+
+namespace mcn { bool tuning_sarl_x3() { return tuning().sarl_x3 != 0; } }
+
+// bf16 round-to-nearest-even of a float32 (NaN kept quiet), as the device's v_cvt_pk_bf16_f32
+static uint16_t bf16_rne(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float bf16_to_f32(uint16_t h) { const uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+int64_t mcn_pack_x3_bytes(int32_t NT, int32_t KT)
+{
+    if (NT <= 0 || KT <= 0) return 0;
+    return (int64_t)NT * ((KT + 1) / 2) * 3 * 64 * 8 * 2;
+}
+
+int mcn_pack_x3(const float *wfrag, int32_t NT, int32_t KT, void *x3_out)
+{
+    if (!wfrag || !x3_out || NT <= 0 || KT <= 0) return MCN_EINVAL;
+    const int KB = (KT + 1) / 2;
+    uint16_t *out = reinterpret_cast<uint16_t *>(x3_out);
+    for (int n = 0; n < NT; ++n)
+        for (int m = 0; m < KB; ++m)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int s = 0; s < 8; ++s) {
+                    // k-slot 8 q + s of input block m = slot 4 q + (s & 3) of k-tile 2 m + (s >> 2)
+                    const int t = 2 * m + (s >> 2);
+                    const float w = t < KT ? wfrag[(((size_t)n * KT + t) * 64 + lane) * 4 + (s & 3)] : 0.0f;
+                    const uint16_t hi = bf16_rne(w);
+                    const float r1 = w - bf16_to_f32(hi);
+                    const uint16_t mid = bf16_rne(r1);
+                    const float r2 = r1 - bf16_to_f32(mid);
+                    const size_t at = (((size_t)n * KB + m) * 3 * 64 + lane) * 8 + s;
+                    out[at] = hi; out[at + 64 * 8] = mid; out[at + 2 * 64 * 8] = bf16_rne(r2);
+                }
+    return MCN_OK;
 }
 
 // mcn_last_dispatch(): the launch functions of the env kernels note which family they picked (per host thread).
@@ -95,6 +137,7 @@ int64_t mcn_sizeof(int32_t which)
         case MCN_SIZEOF_SCENARIO_CFG: return sizeof(mcn_scenario_cfg);
         case MCN_SIZEOF_MLP_WORLD_NET: return sizeof(mcn_mlp_world_net);
         case MCN_SIZEOF_ATTN_WORLD_NET: return sizeof(mcn_attn_world_net);
+        case MCN_SIZEOF_SARL_X3: return sizeof(mcn_sarl_x3);
         default: return -1;
     }
 }
@@ -166,6 +209,7 @@ int mcn_set_tuning(const mcn_tuning *t)
     if (t->quad_max_envs < -1 || t->quad_split < -1 || t->rollout_fused < -1 || t->rollout_split < -1 || t->pair_stream < -1) return MCN_EINVAL;
     if (t->step_block != -1 && t->step_block != 64 && t->step_block != 256) return MCN_EINVAL;
     if (t->lp3_defer < -1 || t->lp3_defer > 1) return MCN_EINVAL;
+    if (t->sarl_x3 < -1 || t->sarl_x3 > 1) return MCN_EINVAL;
 #ifndef MCN_DIAG
     if (t->diag_noop) return MCN_EINVAL;          // kernels that do nothing exist in the diagnostic build only
 #endif

@@ -525,4 +525,149 @@ __device__ __forceinline__ void dense_flow(const f32x4 (&in)[KT], const f32x4 *i
     F.parity = (F.parity + NCH) & 1;
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16x3: float32 layers on the bf16 matrix pipe (round 4).
+// A float32 value is split exactly into three bfloat16 pieces, x = hi + mid + lo (8 + 8 + 8 significand bits); of the
+// nine piece products of w * x six are kept (everything down to 2^-24 relative: hi hi, hi mid, mid hi, hi lo, lo hi,
+// mid mid) and accumulated in float32 by v_mfma_f32_16x16x32_bf16 -- 16 cycles per instruction and 32 features deep,
+// i.e. 96 cycles per 32 x 16 block against 256 for the eight v_mfma_f32_16x16x4_f32 it replaces, and, unlike the
+// float32 form, the bf16 form leaves the vector ALU free for the splitting while it runs.  Measured error against a
+// float64 evaluation: the same as the float32 MFMA chain's (tools/microbench/split_bf16.hip, profiles/r02_split_bf16.txt).
+// Register chaining carries over: a lane's accumulators of output tiles 2m and 2m + 1 (features 4q + r of each) are,
+// as they stand, the eight k-slots 8q + s of the B operand of input block m, so `split8` of two finished output tiles
+// IS the next layer's operand; the weight fragments are the float32 fragments of mcn_pack_linear regrouped by
+// mcn_pack_x3: per (output tile, input block) three 16-byte pieces per lane.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct X3 { bf16x8 hi, mid, lo; };
+
+__device__ __forceinline__ X3 split8(const f32x4 a, const f32x4 b)
+{
+    X3 s;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float x = i < 4 ? a[i] : b[i - 4];
+        const __bf16 h = (__bf16)x;
+        const float r1 = x - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        s.hi[i] = h; s.mid[i] = m; s.lo[i] = (__bf16)r2;
+    }
+    return s;
+}
+
+// staged chunk of an x3 layer: whole output tiles, as many as fit the stage with their biases; balanced over the chunks
+__host__ __device__ constexpr int x3_rows(int KB) { return KB * 3 * 64; }                       // 16-byte rows per output tile
+__host__ __device__ constexpr int x3_fit(int KB) { return (kStageFloat4 + kStageBias) / (x3_rows(KB) + 64); }
+__host__ __device__ constexpr int x3_chunks(int KB, int NT) { return (NT + x3_fit(KB) - 1) / x3_fit(KB); }
+__host__ __device__ constexpr int x3_chunk_tiles(int KB, int NT) { return (NT + x3_chunks(KB, NT) - 1) / x3_chunks(KB, NT); }
+__host__ __device__ constexpr int x3_bias_at(int KB, int NT)       // biases start at the next DMA round after the chunk
+{
+    return (x3_chunk_tiles(KB, NT) * x3_rows(KB) + kStageThreads - 1) / kStageThreads * kStageThreads;
+}
+template <int KB, int NT, bool HAS_INIT>
+__device__ __forceinline__ NextChunk first_chunk_x3(const float4 *wf, const float4 *bf)
+{
+    constexpr int CT = x3_chunk_tiles(KB, NT), CH = CT * x3_rows(KB), TOTAL = NT * x3_rows(KB), BCH = CT * 64;
+    static_assert(x3_bias_at(KB, NT) + (HAS_INIT ? 0 : BCH) <= kStageFloat4 + kStageBias, "x3 chunk + biases do not fit the LDS stage");
+    return NextChunk{wf, CH < TOTAL ? CH : TOTAL, HAS_INIT ? nullptr : bf, HAS_INIT ? 0 : (BCH < NT * 64 ? BCH : NT * 64),
+                     x3_bias_at(KB, NT)};
+}
+
+// One layer: in = KB input blocks of 32 features (split), out = NT output tiles of 16 features (float32 accumulators,
+// bias / init added, ReLU applied).  Weight stream, barriers and the hand-over of the following layer's first chunk
+// exactly as dense_flow.
+template <int KB, int NT, bool RELU, bool HAS_INIT>
+__device__ __forceinline__ void dense_flow_x3(const X3 (&in)[KB], const f32x4 *init, f32x4 (&out)[NT],
+                                              const float4 *__restrict__ wf, const float4 *__restrict__ bf,
+                                              WeightFlow &F, int lane, const NextChunk &next)
+{
+    constexpr int CT = x3_chunk_tiles(KB, NT);
+    constexpr int ROWS = x3_rows(KB);
+    constexpr int CH = CT * ROWS;
+    constexpr int TOTAL = NT * ROWS;
+    constexpr int NCH = x3_chunks(KB, NT);
+    constexpr int PER = (CH + kStageThreads - 1) / kStageThreads;
+    constexpr int BOFF = x3_bias_at(KB, NT);
+    constexpr int BCH = CT * 64;
+    constexpr int BPER = (BCH + kStageThreads - 1) / kStageThreads;
+    static_assert(BOFF + (HAS_INIT ? 0 : BCH) <= kStageFloat4 + kStageBias, "x3 chunk + biases do not fit the LDS stage");
+    float4 *const bufp[2] = {F.buf + F.parity * kStageBuf, F.buf + (F.parity ^ 1) * kStageBuf};
+    auto stage = [&](int c) {                             // chunk c >= 1 of THIS layer -> buffer (parity + c) & 1
+        int tid_ = F.tid;
+        asm volatile("" : "+v"(tid_));
+        const int wave_base = tid_ & ~63;
+        float4 *dst = bufp[c & 1];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            int i = c * CH + tid_ + k * kStageThreads;
+            i = i < TOTAL - 1 ? i : TOTAL - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wf + i),
+                                             (__attribute__((address_space(3))) void *)(dst + k * kStageThreads + wave_base),
+                                             16, 0, 0);
+        }
+        if (!HAS_INIT) {
+#pragma unroll
+            for (int k = 0; k < BPER; ++k) {
+                int i = c * BCH + tid_ + k * kStageThreads;
+                i = i < NT * 64 - 1 ? i : NT * 64 - 1;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bf + i),
+                                                 (__attribute__((address_space(3))) void *)(dst + BOFF + k * kStageThreads + wave_base),
+                                                 16, 0, 0);
+            }
+        }
+    };
+    constexpr int NG = NT * KB;                           // groups: (output tile, input block), six MFMAs each
+    float4 ra[2][3], bias = make_float4(0, 0, 0, 0);
+    auto issue = [&](int g) {
+        const int n = g / KB, m = g - n * KB;
+        const int c = n / CT, h = n - c * CT;
+        const float4 *w = bufp[c & 1] + (h * KB + m) * 192;
+        ra[g & 1][0] = w[lane]; ra[g & 1][1] = w[64 + lane]; ra[g & 1][2] = w[128 + lane];
+        if (m == 0 && !HAS_INIT) bias = bufp[c & 1][BOFF + h * 64 + lane];
+    };
+    issue(0);
+    f32x4 a = {0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int n = g / KB, m = g - n * KB;
+        const int c = n / CT;
+        const bool chunk_first = (m == 0) && (n == c * CT);
+        const bool chunk_last = (m == KB - 1) && ((n == c * CT + CT - 1) || (n == NT - 1));
+        if (chunk_first && chunk_last) {
+            if (c + 1 < NCH) stage(c + 1);
+            else if (next.n_w > 0) flow_stage_first(F, next, (F.parity + NCH) & 1);
+        }
+        if (chunk_last) __syncthreads();
+        if (m == 0) {
+            if (HAS_INIT) a = init[n];
+            else a = (f32x4){bias.x, bias.y, bias.z, bias.w};
+        }
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, ra[g & 1][0]), wm = __builtin_bit_cast(bf16x8, ra[g & 1][1]),
+                     wl = __builtin_bit_cast(bf16x8, ra[g & 1][2]);
+        __builtin_amdgcn_sched_barrier(0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, in[m].hi, a, 0, 0, 0);            // smallest terms first
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < NG) issue(g + 1);
+        if (chunk_first && !chunk_last) {
+            if (c + 1 < NCH) stage(c + 1);
+            else if (next.n_w > 0) flow_stage_first(F, next, (F.parity + NCH) & 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, in[m].lo, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, in[m].mid, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, in[m].hi, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, in[m].mid, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, in[m].hi, a, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (m == KB - 1) {
+            if (RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = relu_f32(a[r]);
+            }
+            out[n] = a;
+        }
+    }
+    F.parity = (F.parity + NCH) & 1;
+}
+
 }  // namespace mcn

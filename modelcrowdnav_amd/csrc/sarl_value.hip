@@ -36,12 +36,14 @@
 // reference's operation order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "../../include/mcn.h"
 #include "mfma_chain.hpp"
 #include "fast_f32.hpp"
 
 namespace mcn {
 
+bool tuning_sarl_x3();              // mcn_api.hip: mcn_tuning.sarl_x3 (-1 / 1: use the x3 fragments when given, 0: never)
 
 // tiles of 16 features
 constexpr int T13 = 1, T150 = 10, T100 = 7, T50 = 4, T56 = 5 /* pooled 4 + self 1 */, T1 = 1;
@@ -63,8 +65,17 @@ struct SarlFrags {
     const float4 *w_m3d, *b_m3d;   // 100 -> 1
 };
 
+// bf16x3 weight fragments (mcn_pack_x3 of the float32 fragments above; biases stay the float32 ones): NULL table = float32 MFMA
+struct SarlX3 {
+    const float4 *w_m1a, *w_m1b, *w_m2a, *w_m2b, *w_ata, *w_atg, *w_atb, *w_atc, *w_m3a, *w_m3b, *w_m3c, *w_m3d;
+};
+// 32-feature input blocks of the x3 layers
+constexpr int B13 = 1, B150 = 5, B100 = 4, B56 = 3;
+constexpr int kWsRowsF32 = T100, kWsRowsX3 = B100 * 3;      // 16-byte workspace rows per human and lane: float32 tiles / x3 pieces
+
 struct SarlParams {
     SarlFrags f;
+    SarlX3 x;
     // state (same buffers as mcn_env_state)
     const double *rpos, *rvel, *rgoal, *rrad, *rvpref, *rtheta;   // [E][2] / [E]
     const double *hpos, *hvel, *hrad;                             // [E*N][2] / [E*N]
@@ -127,6 +138,9 @@ constexpr int kSarlWaves = kStageThreads / 64;     // 8 wavefronts share one LDS
     dense_staged<KT, NT, RELU, INIT, L1, L2>(in, init, out, w, b, S, lane)
 #endif
 
+// USE_X3 = false: float32 MFMA layers (v_mfma_f32_16x16x4_f32); USE_X3 = true: the same layers on the bf16 matrix pipe with every
+// operand split into three bfloat16 pieces (mfma_chain.hpp: dense_flow_x3) -- float32-accurate, ~2.7 x fewer pipe cycles.
+template <bool USE_X3>
 __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl_value_kernel(const SarlParams p)
 {
     __shared__ float4 s_stage[2 * (kStageFloat4 + kStageBias)];
@@ -134,13 +148,16 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
     const int N = p.N;
 #if MCN_SARL_FLOW
     // chunk 0 of every layer, as the layer before it requests it
-    const NextChunk d_m1a = first_chunk<T13, T150, false>(p.f.w_m1a, p.f.b_m1a), d_m1b = first_chunk<T150, T100, false>(p.f.w_m1b, p.f.b_m1b);
-    const NextChunk d_atg = first_chunk<T100, T100, false>(p.f.w_atg, p.f.b_ata), d_ata = first_chunk<T100, T100, true>(p.f.w_ata, nullptr);
-    const NextChunk d_atb = first_chunk<T100, T100, false>(p.f.w_atb, p.f.b_atb), d_atc = first_chunk<T100, T1, false>(p.f.w_atc, p.f.b_atc);
-    const NextChunk d_m2a = first_chunk<T100, T100, false>(p.f.w_m2a, p.f.b_m2a), d_m2b = first_chunk<T100, T50, false>(p.f.w_m2b, p.f.b_m2b);
-    const NextChunk d_m3a = first_chunk<T56, T150, false>(p.f.w_m3a, p.f.b_m3a), d_m3b = first_chunk<T150, T100, false>(p.f.w_m3b, p.f.b_m3b);
-    const NextChunk d_m3c = first_chunk<T100, T100, false>(p.f.w_m3c, p.f.b_m3c), d_m3d = first_chunk<T100, T1, false>(p.f.w_m3d, p.f.b_m3d);
-    const NextChunk d_none = {nullptr, 0, nullptr, 0};
+#define SARL_FIRST(KT, KB, NT, INIT, name, bias)                                                              \
+    (USE_X3 ? first_chunk_x3<KB, NT, INIT>(p.x.w_##name, bias) : first_chunk<KT, NT, INIT>(p.f.w_##name, bias))
+    const NextChunk d_m1a = SARL_FIRST(T13, B13, T150, false, m1a, p.f.b_m1a), d_m1b = SARL_FIRST(T150, B150, T100, false, m1b, p.f.b_m1b);
+    const NextChunk d_atg = SARL_FIRST(T100, B100, T100, false, atg, p.f.b_ata), d_ata = SARL_FIRST(T100, B100, T100, true, ata, nullptr);
+    const NextChunk d_atb = SARL_FIRST(T100, B100, T100, false, atb, p.f.b_atb), d_atc = SARL_FIRST(T100, B100, T1, false, atc, p.f.b_atc);
+    const NextChunk d_m2a = SARL_FIRST(T100, B100, T100, false, m2a, p.f.b_m2a), d_m2b = SARL_FIRST(T100, B100, T50, false, m2b, p.f.b_m2b);
+    const NextChunk d_m3a = SARL_FIRST(T56, B56, T150, false, m3a, p.f.b_m3a), d_m3b = SARL_FIRST(T150, B150, T100, false, m3b, p.f.b_m3b);
+    const NextChunk d_m3c = SARL_FIRST(T100, B100, T100, false, m3c, p.f.b_m3c), d_m3d = SARL_FIRST(T100, B100, T1, false, m3d, p.f.b_m3d);
+#undef SARL_FIRST
+    const NextChunk d_none = {nullptr, 0, nullptr, 0, 0};
     WeightFlow F{s_stage, (int)threadIdx.x, 0};
     if ((long)blockIdx.x < p.ngroups) flow_stage_first(F, d_m1a, 0);         // the very first layer of this workgroup
     __syncthreads();
@@ -157,7 +174,8 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
     const int wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
     // this wavefront's workspace slot: by resident wavefront (persistent grid), reused for every tile it walks over
-    float4 *const ws = p.workspace + ((long)blockIdx.x * kSarlWaves + wave) * (long)N * T100 * 64;
+    constexpr int WSR = USE_X3 ? kWsRowsX3 : kWsRowsF32;                   // 16-byte rows per human and lane
+    float4 *const ws = p.workspace + ((long)blockIdx.x * kSarlWaves + wave) * (long)N * WSR * 64;
     const long pair0 = (grp * kSarlWaves + wave) * 16;
     SARL_T0();
     // no early exit: every wavefront of the workgroup takes part in the weight staging barriers
@@ -242,15 +260,39 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
             x[0][r] = q == 0 ? feat[r] : (q == 1 ? feat[4 + r] : (q == 2 ? feat[8 + r] : feat[12 + r]));
         SARL_PHASE(1);                  // per human: state loads, float64 distance, rotated features
         f32x4 h1[T150];
+        f32x4 h2[T100];
+        const f32x4 zero4 = {0, 0, 0, 0};
+        if constexpr (USE_X3) {
+            const X3 xin[B13] = {split8(x[0], zero4)};
+            dense_flow_x3<B13, T150, true, false>(xin, nullptr, h1, p.x.w_m1a, reinterpret_cast<const float4 *>(p.f.b_m1a), F, lane, d_m1b);
+            SARL_PHASE(2);              // mlp1.0
+            X3 h1p[B150];
+#pragma unroll
+            for (int m = 0; m < B150; ++m) h1p[m] = split8(h1[2 * m], h1[2 * m + 1]);
+            dense_flow_x3<B150, T100, true, false>(h1p, nullptr, h2, p.x.w_m1b, reinterpret_cast<const float4 *>(p.f.b_m1b), F, lane,
+                                                  (i + 1 < N ? d_m1a : d_atg));
+            SARL_PHASE(3);              // mlp1.2
+            // the workspace keeps mlp1's output already split: pass 2 reads the pieces twice (attention.0, mlp2.0)
+#pragma unroll
+            for (int m = 0; m < B100; ++m) {
+                const X3 pc = split8(h2[2 * m], 2 * m + 1 < T100 ? h2[2 * m + 1] : zero4);
+                ws[(i * WSR + 3 * m + 0) * 64 + lane] = __builtin_bit_cast(float4, pc.hi);
+                ws[(i * WSR + 3 * m + 1) * 64 + lane] = __builtin_bit_cast(float4, pc.mid);
+                ws[(i * WSR + 3 * m + 2) * 64 + lane] = __builtin_bit_cast(float4, pc.lo);
+            }
+#pragma unroll
+            for (int t = 0; t < T100; ++t)
+                if (i < ne) gsum[t] += h2[t];
+        } else {
         SARL_LAYER(T13, T150, true, false, 4, 4, x, nullptr, h1, p.f.w_m1a, p.f.b_m1a, d_m1b);
         SARL_PHASE(2);                  // mlp1.0
-        f32x4 h2[T100];
         SARL_LAYER(T150, T100, true, false, 2, 4, h1, nullptr, h2, p.f.w_m1b, p.f.b_m1b, (i + 1 < N ? d_m1a : d_atg));
         SARL_PHASE(3);                  // mlp1.2
 #pragma unroll
         for (int t = 0; t < T100; ++t) {
             ws[(i * T100 + t) * 64 + lane] = make_float4(h2[t][0], h2[t][1], h2[t][2], h2[t][3]);
             if (i < ne) gsum[t] += h2[t];
+        }
         }
         SARL_PHASE(4);                  // workspace store, global-state sum
     }
@@ -273,7 +315,15 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
 #pragma unroll
         for (int r = 0; r < 4; ++r) gsum[t][r] = gsum[t][r] * inv_n;
     f32x4 gat[T100];
+    const f32x4 zero4 = {0, 0, 0, 0};
+    if constexpr (USE_X3) {
+        X3 gp[B100];
+#pragma unroll
+        for (int m = 0; m < B100; ++m) gp[m] = split8(gsum[2 * m], 2 * m + 1 < T100 ? gsum[2 * m + 1] : zero4);
+        dense_flow_x3<B100, T100, false, false>(gp, nullptr, gat, p.x.w_atg, reinterpret_cast<const float4 *>(p.f.b_ata), F, lane, d_ata);
+    } else {
     SARL_LAYER(T100, T100, false, false, 1, 4, gsum, nullptr, gat, p.f.w_atg, p.f.b_ata, d_ata);
+    }
     SARL_PHASE(5);                      // reward ladder, mean, global half of attention.0
 
     // ---- pass 2: attention score, mlp2, pooling ----
@@ -291,20 +341,44 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
         const WeightStage S{s_stage, tid_i};
         (void)S;
         f32x4 h2[T100];
+        f32x4 a1[T100];
+        f32x4 a2[T100];
+        f32x4 sc[T1];
+        auto load_pieces = [&](X3 (&dst)[B100]) {          // mlp1's output of human i, as pass 1 split it
+#pragma unroll
+            for (int m = 0; m < B100; ++m) {
+                dst[m].hi = __builtin_bit_cast(bf16x8, ws[(i * WSR + 3 * m + 0) * 64 + lane]);
+                dst[m].mid = __builtin_bit_cast(bf16x8, ws[(i * WSR + 3 * m + 1) * 64 + lane]);
+                dst[m].lo = __builtin_bit_cast(bf16x8, ws[(i * WSR + 3 * m + 2) * 64 + lane]);
+            }
+        };
+        if constexpr (USE_X3) {
+            X3 hp[B100];
+            load_pieces(hp);
+            SARL_PHASE(6);              // workspace load
+            dense_flow_x3<B100, T100, true, true>(hp, gat, a1, p.x.w_ata, nullptr, F, lane, d_atb);
+            SARL_PHASE(7);              // attention.0
+            X3 ap[B100];
+#pragma unroll
+            for (int m = 0; m < B100; ++m) ap[m] = split8(a1[2 * m], 2 * m + 1 < T100 ? a1[2 * m + 1] : zero4);
+            dense_flow_x3<B100, T100, true, false>(ap, nullptr, a2, p.x.w_atb, reinterpret_cast<const float4 *>(p.f.b_atb), F, lane, d_atc);
+            SARL_PHASE(8);              // attention.2
+#pragma unroll
+            for (int m = 0; m < B100; ++m) ap[m] = split8(a2[2 * m], 2 * m + 1 < T100 ? a2[2 * m + 1] : zero4);
+            dense_flow_x3<B100, T1, false, false>(ap, nullptr, sc, p.x.w_atc, reinterpret_cast<const float4 *>(p.f.b_atc), F, lane, d_m2a);
+        } else {
 #pragma unroll
         for (int t = 0; t < T100; ++t) {
             const float4 v = ws[(i * T100 + t) * 64 + lane];
             h2[t] = (f32x4){v.x, v.y, v.z, v.w};
         }
         SARL_PHASE(6);                  // workspace load
-        f32x4 a1[T100];
         SARL_LAYER(T100, T100, true, true, 1, 4, h2, gat, a1, p.f.w_ata, nullptr, d_atb);
         SARL_PHASE(7);                  // attention.0
-        f32x4 a2[T100];
         SARL_LAYER(T100, T100, true, false, 1, 4, a1, nullptr, a2, p.f.w_atb, p.f.b_atb, d_atc);
         SARL_PHASE(8);                  // attention.2
-        f32x4 sc[T1];
         SARL_LAYER(T100, T1, false, false, 1, 4, a2, nullptr, sc, p.f.w_atc, p.f.b_atc, d_m2a);
+        }
         SARL_PHASE(9);                  // attention.4
         // score of pair j sits in lane j (q = 0), register 0; broadcast to the pair's four lanes
         const float s = __shfl(sc[0][0], j);
@@ -313,7 +387,14 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
         denom += es;
         SARL_PHASE(10);                 // exp, attention output
         f32x4 m1[T100];
+        if constexpr (USE_X3) {
+            X3 hp[B100];
+            load_pieces(hp);            // (read again rather than kept: 48 registers across the attention layers)
+            dense_flow_x3<B100, T100, true, false>(hp, nullptr, m1, p.x.w_m2a, reinterpret_cast<const float4 *>(p.f.b_m2a), F, lane,
+                                                  (i + 1 < N ? d_ata : d_m2b));
+        } else {
         SARL_LAYER(T100, T100, true, false, 1, 4, h2, nullptr, m1, p.f.w_m2a, p.f.b_m2a, (i + 1 < N ? d_ata : d_m2b));
+        }
         SARL_PHASE(11);                 // mlp2.0
 #pragma unroll
         for (int t = 0; t < T100; ++t)
@@ -332,7 +413,14 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
 #pragma unroll
             for (int r = 0; r < 4; ++r) racc[t][r] = racc[t][r] * inv_d;
         f32x4 pooled[T50];
+        if constexpr (USE_X3) {
+            X3 rp3[B100];
+#pragma unroll
+            for (int m = 0; m < B100; ++m) rp3[m] = split8(racc[2 * m], 2 * m + 1 < T100 ? racc[2 * m + 1] : zero4);
+            dense_flow_x3<B100, T50, false, false>(rp3, nullptr, pooled, p.x.w_m2b, reinterpret_cast<const float4 *>(p.f.b_m2b), F, lane, d_m3a);
+        } else {
         SARL_LAYER(T100, T50, false, false, 1, 4, racc, nullptr, pooled, p.f.w_m2b, p.f.b_m2b, d_m3a);
+        }
 #pragma unroll
         for (int t = 0; t < T50; ++t) jin[t] = pooled[t];
     }
@@ -344,13 +432,31 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
     }
     SARL_PHASE(13);                     // normalise, mlp2.2, self tile
     f32x4 v1[T150];
-    SARL_LAYER(T56, T150, true, false, 2, 1, jin, nullptr, v1, p.f.w_m3a, p.f.b_m3a, d_m3b);
     f32x4 v2[T100];
-    SARL_LAYER(T150, T100, true, false, 2, 4, v1, nullptr, v2, p.f.w_m3b, p.f.b_m3b, d_m3c);
     f32x4 v3[T100];
-    SARL_LAYER(T100, T100, true, false, 1, 4, v2, nullptr, v3, p.f.w_m3c, p.f.b_m3c, d_m3d);
     f32x4 vo[T1];
+    if constexpr (USE_X3) {
+        X3 jp[B56];                     // input blocks: (pooled tiles 0, 1), (pooled tiles 2, 3), (self tile, -)
+        jp[0] = split8(jin[0], jin[1]); jp[1] = split8(jin[2], jin[3]); jp[2] = split8(jin[4], zero4);
+        dense_flow_x3<B56, T150, true, false>(jp, nullptr, v1, p.x.w_m3a, reinterpret_cast<const float4 *>(p.f.b_m3a), F, lane, d_m3b);
+        X3 vp[B150];
+#pragma unroll
+        for (int m = 0; m < B150; ++m) vp[m] = split8(v1[2 * m], v1[2 * m + 1]);
+        dense_flow_x3<B150, T100, true, false>(vp, nullptr, v2, p.x.w_m3b, reinterpret_cast<const float4 *>(p.f.b_m3b), F, lane, d_m3c);
+        X3 wp[B100];
+#pragma unroll
+        for (int m = 0; m < B100; ++m) wp[m] = split8(v2[2 * m], 2 * m + 1 < T100 ? v2[2 * m + 1] : zero4);
+        dense_flow_x3<B100, T100, true, false>(wp, nullptr, v3, p.x.w_m3c, reinterpret_cast<const float4 *>(p.f.b_m3c), F, lane, d_m3d);
+#pragma unroll
+        for (int m = 0; m < B100; ++m) wp[m] = split8(v3[2 * m], 2 * m + 1 < T100 ? v3[2 * m + 1] : zero4);
+        dense_flow_x3<B100, T1, false, false>(wp, nullptr, vo, p.x.w_m3d, reinterpret_cast<const float4 *>(p.f.b_m3d), F, lane,
+                                             (grp + gridDim.x < p.ngroups ? d_m1a : d_none));
+    } else {
+    SARL_LAYER(T56, T150, true, false, 2, 1, jin, nullptr, v1, p.f.w_m3a, p.f.b_m3a, d_m3b);
+    SARL_LAYER(T150, T100, true, false, 2, 4, v1, nullptr, v2, p.f.w_m3b, p.f.b_m3b, d_m3c);
+    SARL_LAYER(T100, T100, true, false, 1, 4, v2, nullptr, v3, p.f.w_m3c, p.f.b_m3c, d_m3d);
     SARL_LAYER(T100, T1, false, false, 1, 4, v3, nullptr, vo, p.f.w_m3d, p.f.b_m3d, (grp + gridDim.x < p.ngroups ? d_m1a : d_none));
+    }
     if (valid && q == 0) {
         // value = reward + gamma^(dt * v_pref) * V   (multi_human_rl.py:52, Python float arithmetic)
         p.values[pair] = reward + p.gamma_pow * (double)vo[0][0];
@@ -431,7 +537,11 @@ int launch_sarl(SarlParams &p, int32_t *best, double *best_val, double *action_o
     const long waves = (npairs + 15) / 16;
     p.ngroups = (waves + kSarlWaves - 1) / kSarlWaves;
     const int blocks = (int)(p.ngroups < kSarlMaxBlocks ? p.ngroups : kSarlMaxBlocks);
-    hipLaunchKernelGGL(sarl_value_kernel, dim3(blocks), dim3(kSarlWaves * 64), 0, stream, p);
+#if MCN_SARL_FLOW
+    if (p.x.w_m1a) hipLaunchKernelGGL(sarl_value_kernel<true>, dim3(blocks), dim3(kSarlWaves * 64), 0, stream, p);
+    else
+#endif
+    hipLaunchKernelGGL(sarl_value_kernel<false>, dim3(blocks), dim3(kSarlWaves * 64), 0, stream, p);
     if (best) {
         hipLaunchKernelGGL(sarl_argmax_kernel, dim3(p.E), dim3(64), 0, stream, p.values, p.rpos, p.rgoal, p.rrad,
                            p.E, p.A, best, best_val, p.actions, action_out, epsilon, seed);
@@ -447,8 +557,11 @@ int launch_sarl_c(const mcn_sarl_net *net, const mcn_env_state *st, const double
     SarlParams p;
     const float4 *const *src = reinterpret_cast<const float4 *const *>(net);
     const float4 **dst = reinterpret_cast<const float4 **>(&p.f);
-    static_assert(sizeof(SarlFrags) == sizeof(mcn_sarl_net), "fragment tables must mirror the C struct");
-    for (size_t k = 0; k < sizeof(mcn_sarl_net) / sizeof(float *); ++k) dst[k] = src[k];
+    static_assert(sizeof(SarlFrags) + sizeof(void *) == sizeof(mcn_sarl_net), "fragment tables must mirror the C struct");
+    static_assert(sizeof(SarlX3) == sizeof(mcn_sarl_x3), "x3 fragment tables must mirror the C struct");
+    for (size_t k = 0; k < sizeof(SarlFrags) / sizeof(float *); ++k) dst[k] = src[k];
+    memset(&p.x, 0, sizeof(p.x));
+    if (net->x3 && tuning_sarl_x3()) memcpy(&p.x, net->x3, sizeof(p.x));
     p.rpos = st->rpos; p.rvel = st->rvel; p.rgoal = st->rgoal; p.rrad = st->rrad; p.rvpref = st->rvpref; p.rtheta = st->rtheta;
     p.hpos = st->hpos; p.hvel = st->hvel; p.hrad = st->hrad; p.hcount = st->hcount;
     p.next_hpos = next_hpos; p.next_hvel = next_hvel; p.reward_in = reward_in;
@@ -463,7 +576,7 @@ long sarl_workspace_float4s(int E, int N, int A)
     const long waves = ((long)E * A + 15) / 16;
     long groups = (waves + kSarlWaves - 1) / kSarlWaves;
     if (groups > kSarlMaxBlocks) groups = kSarlMaxBlocks;          // one slot per RESIDENT wavefront
-    return groups * kSarlWaves * (long)N * T100 * 64;
+    return groups * kSarlWaves * (long)N * (kWsRowsX3 > kWsRowsF32 ? kWsRowsX3 : kWsRowsF32) * 64;
 }
 
 }  // namespace mcn

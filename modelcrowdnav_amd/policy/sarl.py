@@ -89,10 +89,17 @@ def _pack_plan():
             ("m3d", "mlp3.6", _ident(100, 7), 7, True)]
 
 
+class _SarlX3(C.Structure):
+    """mcn_sarl_x3: device pointers to the bf16x3 weight fragments (mcn_pack_x3)."""
+    _fields_ = [(n, C.c_void_p) for n in ("w_m1a", "w_m1b", "w_m2a", "w_m2b", "w_ata", "w_atg", "w_atb", "w_atc",
+                                          "w_m3a", "w_m3b", "w_m3c", "w_m3d")]
+
+
 class _SarlNet(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w_m1a", "b_m1a", "w_m1b", "b_m1b", "w_m2a", "b_m2a", "w_m2b", "b_m2b",
                                           "w_ata", "b_ata", "w_atg", "w_atb", "b_atb", "w_atc", "b_atc",
-                                          "w_m3a", "b_m3a", "w_m3b", "b_m3b", "w_m3c", "b_m3c", "w_m3d", "b_m3d")]
+                                          "w_m3a", "b_m3a", "w_m3b", "b_m3b", "w_m3c", "b_m3c", "w_m3d", "b_m3d",
+                                          "x3")]
 
 
 def pack_value_network(model, dev):
@@ -106,6 +113,7 @@ def pack_value_network(model, dev):
             raise ValueError("sarl_value.hip is built for the shipped SARL dimensions (policy.config:44-50); "
                              "%s.weight is %s, expected %s" % (k, sd[k + ".weight"].shape, shp))
     net, keep = _SarlNet(), []
+    x3 = _SarlX3()
     fp = C.POINTER(C.c_float)
     for name, key, kmap, KT, with_bias in _pack_plan():
         W, b = sd[key + ".weight"], sd[key + ".bias"]
@@ -126,6 +134,14 @@ def pack_value_network(model, dev):
             db = torch.from_numpy(bf).to(dev)
             keep.append(db)
             setattr(net, "b_" + name, db.data_ptr())
+        # the same fragments as three bfloat16 pieces per weight, for the bf16 matrix pipe (include/mcn.h: mcn_pack_x3)
+        xb = np.zeros(int(_hip.lib.mcn_pack_x3_bytes(NT, KT)), np.uint8)
+        _hip.check(_hip.lib.mcn_pack_x3(wf.ctypes.data_as(fp), NT, KT, xb.ctypes.data), "mcn_pack_x3(%s)" % name)
+        dx = torch.from_numpy(xb).to(dev)
+        keep.append(dx)
+        setattr(x3, "w_" + name, dx.data_ptr())
+    keep.append(x3)                                     # the host struct mcn_sarl_net.x3 points at
+    net.x3 = C.addressof(x3)
     return net, keep
 
 

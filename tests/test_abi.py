@@ -29,7 +29,7 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(_hip.EnvCfg) == 7 * 8 + 2 * 4 + 6 * 4
     assert ctypes.sizeof(_hip.EnvState) == 14 * 8 and _hip.EnvState.hcount.offset == 13 * 8
     assert ctypes.sizeof(_hip.EnvOut) == 5 * 8 and _hip.EnvOut.lp3_queue.offset == 32
-    assert ctypes.sizeof(_hip.Tuning) == 9 * 4
+    assert ctypes.sizeof(_hip.Tuning) == 10 * 4
     assert ctypes.sizeof(_hip.StepRec) == 24 and _hip.StepRec.done.offset == 16 and _hip.StepRec.hh_count.offset == 20
     assert ctypes.sizeof(_hip.RollRec) == 32 and _hip.RollRec.fin_count.offset == 12
     assert _hip.RollRec.danger_dist_sum.offset == 24
@@ -108,3 +108,28 @@ def test_abi_version_and_struct_sizes_are_checked_against_the_library():
     with pytest.raises(ImportError):
         _hip._check_abi(Old())
     assert _hip.last_dispatch() == ""                    # nothing launched in this process yet
+
+
+def test_pack_x3_splits_every_weight_into_three_bfloat16_pieces():
+    """mcn_pack_x3 (host helper, include/mcn.h): float32 fragments [NT][KT][64][4] -> [NT][ceil(KT / 2)][3][64][8]
+    bfloat16; hi + mid + lo reproduces the float32 weight exactly (3 x 8 significand bits cover its 24), slot 8 q + s
+    of input block m is slot 4 q + (s & 3) of k-tile 2 m + (s >> 2), an odd last k-tile is zero-padded."""
+    import numpy as np
+    from modelcrowdnav_amd import _hip
+    rng = np.random.RandomState(0)
+    for NT, KT in ((3, 7), (2, 10), (1, 1), (4, 5)):
+        wf = (rng.normal(0, 1, (NT, KT, 64, 4)) * np.exp(rng.uniform(-20, 5, (NT, KT, 64, 4)))).astype(np.float32)
+        wf[0, 0, :4, 0] = [0.0, -0.0, 1.0, -3.5]
+        KB = (KT + 1) // 2
+        assert _hip.lib.mcn_pack_x3_bytes(NT, KT) == NT * KB * 3 * 64 * 8 * 2
+        out = np.zeros((NT, KB, 3, 64, 8), np.uint16)
+        assert _hip.lib.mcn_pack_x3(wf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), NT, KT, out.ctypes.data) == 0
+        pieces = (out.astype(np.uint32) << 16).view(np.float32)                  # bfloat16 -> float32, exact
+        total = pieces[:, :, 0].astype(np.float64) + pieces[:, :, 1] + pieces[:, :, 2]
+        want = np.zeros((NT, KB, 64, 8), np.float64)
+        for m in range(KB):
+            for half in range(2):
+                if 2 * m + half < KT:
+                    want[:, m, :, 4 * half:4 * half + 4] = wf[:, 2 * m + half]
+        assert np.array_equal(total, want)                                        # exact: no bit of the weight is lost
+        assert np.all(np.abs(pieces[:, :, 1]) <= np.abs(pieces[:, :, 0]) * 2.0 ** -7 + 1e-45)

@@ -13,26 +13,33 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > "$OUT/counters.txt" 2>&1 || true
 grep -o -i "\b\(TCP_UTCL1[A-Z0-9_]*\|TCC_[A-Z0-9_]*\|TCP_[A-Z0-9_]*STALL[A-Z0-9_]*\|GRBM_GUI_ACTIVE\|TCP_TCC_[A-Z0-9_]*\)\b" "$OUT/counters.txt" | sort -u > "$OUT/names.txt"
 KB="$ROOT/tools/kbench.py"
-run() {  # run <group name> <counters...>
+run() {  # run <group name> <counters...>   (two or three counters per pass: five TCC_*_sum in one pass abort rocprofv3)
   local g=$1; shift
   for E in 1048576 4194304; do
-    rocprofv3 --pmc "$@" --output-format csv -d "$OUT/${g}_$E" -o pmc -- python3 "$KB" --sizes $E --modes given --no-hh --iters 20 \
-        > "$OUT/${g}_$E.log" 2>&1 || { echo "group $g at $E failed:"; tail -3 "$OUT/${g}_$E.log"; }
+    echo "$(date +%T) group $g at $E: $*" >> "$OUT/progress.txt"
+    timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/${g}_$E" -o pmc -- python3 "$KB" --sizes $E --modes given --no-hh --iters 20 \
+        > "$OUT/${g}_$E.log" 2>&1 || { echo "group $g at $E failed" >> "$OUT/progress.txt"; tail -3 "$OUT/${g}_$E.log" >> "$OUT/progress.txt"; }
   done
   echo "group $g done"
 }
 have() { grep -qx "$1" "$OUT/names.txt"; }
 pick() { local o=""; for c in "$@"; do have $c && o="$o $c"; done; echo $o; }
 G1=$(pick TCP_UTCL1_REQUEST TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_TRANSLATION_HIT TCP_UTCL1_PERMISSION_MISS)
-G2=$(pick TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum)
-G3=$(pick TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_TAG_STALL_sum TCC_EA0_RD_UNCACHED_32B_sum)
-G4=$(pick TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum GRBM_GUI_ACTIVE)
-G5=$(pick TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_RDREQ_IO_CREDIT_STALL_sum TCC_EA0_RDREQ_GMI_CREDIT_STALL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum)
-[ -n "$G1" ] && run utcl1 $G1
-[ -n "$G2" ] && run tcc $G2
-[ -n "$G3" ] && run tcc2 $G3
-[ -n "$G4" ] && run tcp $G4
-[ -n "$G5" ] && run ea $G5
+G2=$(pick TCC_HIT_sum TCC_MISS_sum)
+G3=$(pick TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum)
+G4=$(pick TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum)
+G5=$(pick TCC_TAG_STALL_sum TCC_EA0_WRREQ_STALL_sum)
+G6=$(pick TCC_BUSY_sum TCC_CYCLE_sum)
+G7=$(pick TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_WRREQ_LEVEL_sum)
+G8=$(pick TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_SRC_FIFO_FULL_sum)
+[ -n "$G1" ] && [ ! -d "$OUT/utcl1_4194304" ] && run utcl1 $G1
+[ -n "$G2" ] && run tcc_hit $G2
+[ -n "$G3" ] && run tcc_ea $G3
+[ -n "$G4" ] && run tcc_credit $G4
+[ -n "$G5" ] && run tcc_stall $G5
+[ -n "$G6" ] && run tcc_busy $G6
+[ -n "$G7" ] && run tcc_level $G7
+[ -n "$G8" ] && run tcc_fifo $G8
 cd "$ROOT"
 python3 - "$OUT" "$DST/${TAG}_pmc_pair.json" <<'PY'
 import csv, glob, json, os, sys

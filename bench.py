@@ -477,19 +477,49 @@ def sarl_mfma_per_tile(N):
     return N * (40 + 266 + 175 + 175 + 25 + 175) + (175 + 100 + 150 + 266 + 175 + 25)
 
 
+MFMA_BF16_PEAK_TFLOPS = 2516.6   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 = 256 CUs x 4 SIMDs x 2.4 GHz x 1 024 FLOP / cycle
+
+
+def sarl_x3_mfma_per_tile(N):
+    """v_mfma_f32_16x16x32_bf16 instructions sarl_value_kernel<true> issues per 16-pair tile (csrc/mfma_chain.hpp:
+    dense_flow_x3 -- output tiles x 32-feature input blocks x 6 piece products): per human mlp1 10*1*6 + 7*5*6,
+    attention 7*4*6 + 7*4*6 + 1*4*6, mlp2's first layer 7*4*6; per pair the global half of attention.0 7*4*6, mlp2's
+    last layer 4*4*6, mlp3 10*3*6 + 7*5*6 + 7*4*6 + 1*4*6."""
+    return N * (60 + 210 + 168 + 168 + 24 + 168) + (168 + 96 + 180 + 210 + 168 + 24)
+
+
+def sarl_uses_x3():
+    """Whether the look-ahead runs its layers on the bf16 pipe (mcn_sarl_net.x3 is always packed by policy/sarl.py;
+    mcn_tuning.sarl_x3 = 0 / MCN_SARL_X3=0 keeps the float32 MFMA layers)."""
+    from modelcrowdnav_amd import _hip
+    return _hip.get_tuning().sarl_x3 != 0
+
+
 def _sarl_roofline(E, N, ms_net):
-    """`achieved` / `frac` count the FLOP the kernel EXECUTES (MFMAs issued x 2 048, tile padding included); the
-    reference formulation's count (81 x (N x 124 100 + 67 000) per env-step) is reported beside it."""
+    """`achieved` / `frac` count the FLOP the kernel EXECUTES against the dense peak of the matrix instruction it issues
+    (tile padding included).  Since round 4 that is v_mfma_f32_16x16x32_bf16 on bfloat16 PIECES of float32 operands (six
+    piece products per float32 product: float32-accurate), priced against the bf16 peak; what the same
+    time means in float32 terms -- the float32 MFMA instructions the previous kernel issued for the same result, and the
+    reference formulation's count (81 x (N x 124 100 + 67 000) per env-step) -- is reported beside it against
+    the float32 MFMA peak (both can exceed 1: the work no longer runs on that pipe)."""
     reference = 81 * (N * 124100 + 67000) * E
     tiles = (E * 81 + 15) // 16
-    executed = tiles * sarl_mfma_per_tile(N) * 2048
+    f32_equiv = tiles * sarl_mfma_per_tile(N) * 2048
     tr, src = net_traffic("sarl_value_kernel", E, N)
+    if sarl_uses_x3():
+        executed, peak = tiles * sarl_x3_mfma_per_tile(N) * 16384, MFMA_BF16_PEAK_TFLOPS
+        dtype = "f32 operands as 3 x bf16 pieces, f32 accumulate (v_mfma_f32_16x16x32_bf16, 6 piece products)"
+    else:
+        executed, peak, dtype = f32_equiv, MFMA_F32_PEAK_TFLOPS, "f32 (v_mfma_f32_16x16x4_f32)"
     return {"bound": "mfma", "kernel": "mcn::sarl_value_kernel", "achieved": round(executed / ms_net / 1e9, 2),
-            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(executed / ms_net / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
+            "peak": peak, "unit": "TFLOP/s", "frac": round(executed / ms_net / 1e9 / peak, 4),
             "traffic": tr, "traffic_source": src, "executed_flop_per_launch": executed,
+            "f32_mfma_equivalent_flop_per_launch": f32_equiv,
+            "f32_mfma_equivalent_rate": round(f32_equiv / ms_net / 1e9, 2),
+            "f32_mfma_equivalent_rate_over_f32_peak": round(f32_equiv / ms_net / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
             "reference_flop_per_launch": reference, "reference_flop_rate": round(reference / ms_net / 1e9, 2),
             "reference_flop_rate_over_peak": round(reference / ms_net / 1e9 / MFMA_F32_PEAK_TFLOPS, 4),
-            "avg_launch_us": round(ms_net * 1e3, 1), "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}
+            "avg_launch_us": round(ms_net * 1e3, 1), "dtype": dtype}
 
 
 def _sgan_roofline(E, N, ms):

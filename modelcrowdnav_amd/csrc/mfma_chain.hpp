@@ -8,6 +8,8 @@
 // 16-byte load per lane feeds four MFMAs.  float32 MFMA is an exact k-ordered fmaf chain.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
+#include <utility>
 
 namespace mcn {
 
@@ -135,7 +137,12 @@ constexpr int kStageThreads = 64 * MCN_STAGE_WAVES;
 constexpr int kChunkScale = MCN_STAGE_WAVES >= 8 ? 2 : 1;
 __host__ __device__ constexpr int chunk_tiles(int KT) { return kChunkScale * (KT > 16 ? 1 : (KT > 7 ? 2 : 4)); }
 constexpr int kStageFloat4 = kChunkScale * 32 * 64;              // max over layers of chunk_tiles(KT) * KT * 64
-constexpr int kStageBias = kChunkScale * 4 * 64;                 // bias fragments of the chunk's output tiles
+// bias fragments of the chunk's output tiles -- and, for the flow / x3 layers that place their biases themselves, simply
+// the tail of the stage buffer: MCN_STAGE_BIAS_ROWS = 512 makes a buffer 40 KiB (two workgroups then use all 160 KiB)
+#ifndef MCN_STAGE_BIAS_ROWS
+#define MCN_STAGE_BIAS_ROWS 256
+#endif
+constexpr int kStageBias = kChunkScale * MCN_STAGE_BIAS_ROWS;
 
 struct WeightStage {
     float4 *buf;      // LDS, 2 * (kStageFloat4 + kStageBias) float4
@@ -539,6 +546,14 @@ __device__ __forceinline__ void dense_flow(const f32x4 (&in)[KT], const f32x4 *i
 // mcn_pack_x3: per (output tile, input block) three 16-byte pieces per lane.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct X3 { bf16x8 hi, mid, lo; };
+#ifndef MCN_X3_AHEAD
+#define MCN_X3_AHEAD 1
+#endif
+// scheduling fences around the MFMA groups of an x3 layer: 0 = nothing moves across (the split / ReLU blocks of one
+// wavefront then run between its MFMA groups and overlap the OTHER wavefront's MFMAs), 6 = vector / scalar ALU work may
+#ifndef MCN_X3_FENCE
+#define MCN_X3_FENCE 0
+#endif
 
 __device__ __forceinline__ X3 split8(const f32x4 a, const f32x4 b)
 {
@@ -557,7 +572,12 @@ __device__ __forceinline__ X3 split8(const f32x4 a, const f32x4 b)
 
 // staged chunk of an x3 layer: whole output tiles, as many as fit the stage with their biases; balanced over the chunks
 __host__ __device__ constexpr int x3_rows(int KB) { return KB * 3 * 64; }                       // 16-byte rows per output tile
-__host__ __device__ constexpr int x3_fit(int KB) { return (kStageFloat4 + kStageBias) / (x3_rows(KB) + 64); }
+__host__ __device__ constexpr int x3_fit(int KB)          // most output tiles whose rows (rounded up to a DMA round) + biases fit
+{
+    int t = 1;
+    while (((t + 1) * x3_rows(KB) + kStageThreads - 1) / kStageThreads * kStageThreads + (t + 1) * 64 <= kStageFloat4 + kStageBias) ++t;
+    return t;
+}
 __host__ __device__ constexpr int x3_chunks(int KB, int NT) { return (NT + x3_fit(KB) - 1) / x3_fit(KB); }
 __host__ __device__ constexpr int x3_chunk_tiles(int KB, int NT) { return (NT + x3_chunks(KB, NT) - 1) / x3_chunks(KB, NT); }
 __host__ __device__ constexpr int x3_bias_at(int KB, int NT)       // biases start at the next DMA round after the chunk
@@ -574,12 +594,42 @@ __device__ __forceinline__ NextChunk first_chunk_x3(const float4 *wf, const floa
 }
 
 // One layer: in = KB input blocks of 32 features (split), out = NT output tiles of 16 features (float32 accumulators,
-// bias / init added, ReLU applied).  Weight stream, barriers and the hand-over of the following layer's first chunk
-// exactly as dense_flow.
-template <int KB, int NT, bool RELU, bool HAS_INIT>
+// bias / init added, ReLU applied); SPLIT: also outp = the ceil(NT / 2) input blocks of the layer that follows, each
+// split as soon as its two tiles are finished, so that the splitting's vector instructions run in the shadow of the
+// next tiles' MFMAs (a bf16 MFMA holds the vector issue for 8 of its 16 cycles; the scheduling fences below let vector
+// and scalar instructions -- and nothing else -- move across them).  Weight stream and hand-over of the following
+// layer's first chunk as dense_flow; the A pieces are requested TWO groups ahead (a group is only 96 cycles here,
+// less than an LDS round trip under load) into a three-slot register ring, and the chunk barrier sits before the
+// second-to-last group of a chunk (every read of the chunk has been issued by then).
+// init: accumulator start when HAS_INIT -- a register array, or (INIT_MEM) this lane's column of a [NT][64] float4 table
+// in global memory (`init` then points at element [0][lane]; tile n + 1's row is fetched while tile n is multiplied).
+// chunk geometry of an x3 layer in GROUPS (output tile, input block): first / last group of chunk c, and the group before
+// whose MFMAs that chunk's barrier sits (MCN_X3_AHEAD - 1 groups before its last: every read of the chunk issued by then)
+template <int KB, int NT>
+struct X3Geo {
+    static constexpr int CT = x3_chunk_tiles(KB, NT);
+    static constexpr int chunk_of(int g) { return (g / KB) / CT; }
+    static constexpr int first_of(int c) { return c * CT * KB; }
+    static constexpr int last_of(int c) { return ((c + 1) * CT < NT ? (c + 1) * CT : NT) * KB - 1; }
+    static constexpr int barrier_at(int c)
+    {
+        return last_of(c) - (MCN_X3_AHEAD - 1) > first_of(c) ? last_of(c) - (MCN_X3_AHEAD - 1) : first_of(c);
+    }
+};
+template <class Fn, int... Gs>
+__device__ __forceinline__ void static_for(Fn &&f, std::integer_sequence<int, Gs...>)
+{
+    (f(std::integral_constant<int, Gs>{}), ...);
+}
+
+// on_tile(n, a): called with every finished output tile (a consumer that needs each tile once -- a running sum -- does not
+// keep the layer's whole float32 output alive).
+struct NoTileHook { __device__ __forceinline__ void operator()(int, const f32x4 &) const {} };
+template <int KB, int NT, bool RELU, bool HAS_INIT, bool SPLIT = false, bool INIT_MEM = false, class OnTile = NoTileHook>
 __device__ __forceinline__ void dense_flow_x3(const X3 (&in)[KB], const f32x4 *init, f32x4 (&out)[NT],
+                                              X3 (&outp)[(NT + 1) / 2],
                                               const float4 *__restrict__ wf, const float4 *__restrict__ bf,
-                                              WeightFlow &F, int lane, const NextChunk &next)
+                                              WeightFlow &F, int lane, const NextChunk &next, const OnTile &on_tile = OnTile())
 {
     constexpr int CT = x3_chunk_tiles(KB, NT);
     constexpr int ROWS = x3_rows(KB);
@@ -591,6 +641,7 @@ __device__ __forceinline__ void dense_flow_x3(const X3 (&in)[KB], const f32x4 *i
     constexpr int BCH = CT * 64;
     constexpr int BPER = (BCH + kStageThreads - 1) / kStageThreads;
     static_assert(BOFF + (HAS_INIT ? 0 : BCH) <= kStageFloat4 + kStageBias, "x3 chunk + biases do not fit the LDS stage");
+    static_assert(KB * CT >= 2 || NT * KB == 1, "a staged chunk holds at least two groups");
     float4 *const bufp[2] = {F.buf + F.parity * kStageBuf, F.buf + (F.parity ^ 1) * kStageBuf};
     auto stage = [&](int c) {                             // chunk c >= 1 of THIS layer -> buffer (parity + c) & 1
         int tid_ = F.tid;
@@ -617,56 +668,77 @@ __device__ __forceinline__ void dense_flow_x3(const X3 (&in)[KB], const f32x4 *i
         }
     };
     constexpr int NG = NT * KB;                           // groups: (output tile, input block), six MFMAs each
-    float4 ra[2][3], bias = make_float4(0, 0, 0, 0);
-    auto issue = [&](int g) {
-        const int n = g / KB, m = g - n * KB;
-        const int c = n / CT, h = n - c * CT;
+    constexpr int AHEAD = MCN_X3_AHEAD, RING = AHEAD + 1; // groups the A pieces are requested ahead of their use
+    float4 ra[RING][3], bias[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    // (The group loop is a compile-time expansion -- static_for over integral constants -- not an unrolled run-time loop:
+    //  every array index is a constant from the start, so the register promotion of the operand arrays does not depend
+    //  on when the optimiser gets round to unrolling ~50 groups; as a `for` loop the output pieces ended up in scratch.)
+    auto issue = [&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int n = g / KB, m = g - n * KB;
+        constexpr int c = n / CT, h = n - c * CT;
         const float4 *w = bufp[c & 1] + (h * KB + m) * 192;
-        ra[g & 1][0] = w[lane]; ra[g & 1][1] = w[64 + lane]; ra[g & 1][2] = w[128 + lane];
-        if (m == 0 && !HAS_INIT) bias = bufp[c & 1][BOFF + h * 64 + lane];
+        ra[g % RING][0] = w[lane]; ra[g % RING][1] = w[64 + lane]; ra[g % RING][2] = w[128 + lane];
+        if (m == 0 && !HAS_INIT) bias[n & 1] = bufp[c & 1][BOFF + h * 64 + lane];
     };
-    issue(0);
+    auto request_next = [&](int c) {                      // what follows chunk c: this layer's next chunk, or the next layer's first
+        if (c + 1 < NCH) stage(c + 1);
+        else if (next.n_w > 0) flow_stage_first(F, next, (F.parity + NCH) & 1);
+    };
+    issue(std::integral_constant<int, 0>{});
+    if constexpr (AHEAD > 1 && NG > 1 && X3Geo<KB, NT>::chunk_of(1) == 0) issue(std::integral_constant<int, 1>{});
     f32x4 a = {0, 0, 0, 0};
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int n = g / KB, m = g - n * KB;
-        const int c = n / CT;
-        const bool chunk_first = (m == 0) && (n == c * CT);
-        const bool chunk_last = (m == KB - 1) && ((n == c * CT + CT - 1) || (n == NT - 1));
-        if (chunk_first && chunk_last) {
-            if (c + 1 < NCH) stage(c + 1);
-            else if (next.n_w > 0) flow_stage_first(F, next, (F.parity + NCH) & 1);
+    float4 initv[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    if (HAS_INIT && INIT_MEM) initv[0] = reinterpret_cast<const float4 *>(init)[0];
+    auto group = [&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        using Geo = X3Geo<KB, NT>;
+        constexpr int n = g / KB, m = g - n * KB;
+        constexpr int c = Geo::chunk_of(g);
+        constexpr bool at_first = g == Geo::first_of(c), at_barrier = g == Geo::barrier_at(c);
+        if constexpr (at_barrier) {
+            if constexpr (at_first) request_next(c);      // (the request must precede the barrier that publishes it)
+            __syncthreads();                              // every read of chunk c has been issued and is back; DMAs landed
         }
-        if (chunk_last) __syncthreads();
-        if (m == 0) {
-            if (HAS_INIT) a = init[n];
-            else a = (f32x4){bias.x, bias.y, bias.z, bias.w};
+        if constexpr (m == 0) {
+            if constexpr (HAS_INIT && INIT_MEM) {
+                a = (f32x4){initv[n & 1].x, initv[n & 1].y, initv[n & 1].z, initv[n & 1].w};
+                if constexpr (n + 1 < NT) initv[(n + 1) & 1] = reinterpret_cast<const float4 *>(init)[(n + 1) * 64];
+            } else if constexpr (HAS_INIT) a = init[n];
+            else a = (f32x4){bias[n & 1].x, bias[n & 1].y, bias[n & 1].z, bias[n & 1].w};
         }
-        const bf16x8 wh = __builtin_bit_cast(bf16x8, ra[g & 1][0]), wm = __builtin_bit_cast(bf16x8, ra[g & 1][1]),
-                     wl = __builtin_bit_cast(bf16x8, ra[g & 1][2]);
-        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, ra[g % RING][0]), wm = __builtin_bit_cast(bf16x8, ra[g % RING][1]),
+                     wl = __builtin_bit_cast(bf16x8, ra[g % RING][2]);
+        __builtin_amdgcn_sched_barrier(MCN_X3_FENCE);              // vector / scalar ALU work may move across, nothing else
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, in[m].hi, a, 0, 0, 0);            // smallest terms first
-        __builtin_amdgcn_sched_barrier(0);
-        if (g + 1 < NG) issue(g + 1);
-        if (chunk_first && !chunk_last) {
-            if (c + 1 < NCH) stage(c + 1);
-            else if (next.n_w > 0) flow_stage_first(F, next, (F.parity + NCH) & 1);
+        __builtin_amdgcn_sched_barrier(MCN_X3_FENCE);
+        // AHEAD groups ahead -- but never into a chunk whose barrier has not been passed
+        if constexpr (g + AHEAD < NG) {
+            if constexpr (Geo::chunk_of(g + AHEAD) == c || g >= Geo::barrier_at(c)) issue(std::integral_constant<int, g + AHEAD>{});
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (at_first && !at_barrier) request_next(c);
+        __builtin_amdgcn_sched_barrier(MCN_X3_FENCE);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, in[m].lo, a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, in[m].mid, a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, in[m].hi, a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, in[m].mid, a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, in[m].hi, a, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (m == KB - 1) {
+        __builtin_amdgcn_sched_barrier(MCN_X3_FENCE);
+        if constexpr (m == KB - 1) {
             if (RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a[r] = relu_f32(a[r]);
             }
             out[n] = a;
+            on_tile(n, a);
+            if constexpr (SPLIT && ((n & 1) || n == NT - 1)) {
+                const f32x4 z = {0, 0, 0, 0};
+                if constexpr (n & 1) outp[n >> 1] = split8(out[n - 1], out[n]);
+                else outp[n >> 1] = split8(out[n], z);
+            }
         }
-    }
+    };
+    static_for(group, std::make_integer_sequence<int, NG>{});
     F.parity = (F.parity + NCH) & 1;
 }
 

@@ -41,7 +41,26 @@
 #include "mfma_chain.hpp"
 #include "fast_f32.hpp"
 
+// x3 kernel structure switches (A/B): split a layer's output inside the layer, tile pair by tile pair (1), or as one block
+// after it (0); keep the global half of attention.0 in registers (0) or park it in the workspace (1)
+#ifndef MCN_X3_INLOOP_SPLIT
+#define MCN_X3_INLOOP_SPLIT 0
+#endif
+#ifndef MCN_X3_GAT_MEM
+#define MCN_X3_GAT_MEM 0
+#endif
+
 namespace mcn {
+
+constexpr bool kX3In = MCN_X3_INLOOP_SPLIT != 0, kX3GatMem = MCN_X3_GAT_MEM != 0;
+// a layer's output tiles -> the next layer's input blocks, after the layer (when it did not split them itself)
+template <int NT, int NB>
+__device__ __forceinline__ void split_after(const f32x4 (&t)[NT], X3 (&o)[NB])
+{
+    const f32x4 z = {0, 0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < NB; ++m) o[m] = split8(t[2 * m], 2 * m + 1 < NT ? t[2 * m + 1] : z);
+}
 
 bool tuning_sarl_x3();              // mcn_api.hip: mcn_tuning.sarl_x3 (-1 / 1: use the x3 fragments when given, 0: never)
 
@@ -173,9 +192,11 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
+    X3 no4[B100], no2[2], no1[1];       // (output-pieces argument of the x3 layers that hand on float32 tiles only)
     // this wavefront's workspace slot: by resident wavefront (persistent grid), reused for every tile it walks over
     constexpr int WSR = USE_X3 ? kWsRowsX3 : kWsRowsF32;                   // 16-byte rows per human and lane
-    float4 *const ws = p.workspace + ((long)blockIdx.x * kSarlWaves + wave) * (long)N * WSR * 64;
+    // slot of this wavefront: N humans x WSR rows, then (x3) T100 rows for the global half of attention.0
+    float4 *const ws = p.workspace + ((long)blockIdx.x * kSarlWaves + wave) * ((long)N * kWsRowsX3 + T100) * 64;
     const long pair0 = (grp * kSarlWaves + wave) * 16;
     SARL_T0();
     // no early exit: every wavefront of the workgroup takes part in the weight staging barriers
@@ -264,25 +285,23 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
         const f32x4 zero4 = {0, 0, 0, 0};
         if constexpr (USE_X3) {
             const X3 xin[B13] = {split8(x[0], zero4)};
-            dense_flow_x3<B13, T150, true, false>(xin, nullptr, h1, p.x.w_m1a, reinterpret_cast<const float4 *>(p.f.b_m1a), F, lane, d_m1b);
-            SARL_PHASE(2);              // mlp1.0
             X3 h1p[B150];
-#pragma unroll
-            for (int m = 0; m < B150; ++m) h1p[m] = split8(h1[2 * m], h1[2 * m + 1]);
-            dense_flow_x3<B150, T100, true, false>(h1p, nullptr, h2, p.x.w_m1b, reinterpret_cast<const float4 *>(p.f.b_m1b), F, lane,
-                                                  (i + 1 < N ? d_m1a : d_atg));
+            dense_flow_x3<B13, T150, true, false, kX3In>(xin, nullptr, h1, h1p, p.x.w_m1a, reinterpret_cast<const float4 *>(p.f.b_m1a), F, lane, d_m1b);
+            if (!kX3In) split_after(h1, h1p);
+            SARL_PHASE(2);              // mlp1.0
+            X3 h2p[B100];
+            auto add_to_mean = [&](int n, const f32x4 &v) { if (i < ne) gsum[n] += v; };       // global-state sum, tile by tile
+            dense_flow_x3<B150, T100, true, false, kX3In, false>(h1p, nullptr, h2, h2p, p.x.w_m1b, reinterpret_cast<const float4 *>(p.f.b_m1b),
+                                                                F, lane, (i + 1 < N ? d_m1a : d_atg), add_to_mean);
+            if (!kX3In) split_after(h2, h2p);
             SARL_PHASE(3);              // mlp1.2
             // the workspace keeps mlp1's output already split: pass 2 reads the pieces twice (attention.0, mlp2.0)
 #pragma unroll
             for (int m = 0; m < B100; ++m) {
-                const X3 pc = split8(h2[2 * m], 2 * m + 1 < T100 ? h2[2 * m + 1] : zero4);
-                ws[(i * WSR + 3 * m + 0) * 64 + lane] = __builtin_bit_cast(float4, pc.hi);
-                ws[(i * WSR + 3 * m + 1) * 64 + lane] = __builtin_bit_cast(float4, pc.mid);
-                ws[(i * WSR + 3 * m + 2) * 64 + lane] = __builtin_bit_cast(float4, pc.lo);
+                ws[(i * WSR + 3 * m + 0) * 64 + lane] = __builtin_bit_cast(float4, h2p[m].hi);
+                ws[(i * WSR + 3 * m + 1) * 64 + lane] = __builtin_bit_cast(float4, h2p[m].mid);
+                ws[(i * WSR + 3 * m + 2) * 64 + lane] = __builtin_bit_cast(float4, h2p[m].lo);
             }
-#pragma unroll
-            for (int t = 0; t < T100; ++t)
-                if (i < ne) gsum[t] += h2[t];
         } else {
         SARL_LAYER(T13, T150, true, false, 4, 4, x, nullptr, h1, p.f.w_m1a, p.f.b_m1a, d_m1b);
         SARL_PHASE(2);                  // mlp1.0
@@ -320,7 +339,13 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
         X3 gp[B100];
 #pragma unroll
         for (int m = 0; m < B100; ++m) gp[m] = split8(gsum[2 * m], 2 * m + 1 < T100 ? gsum[2 * m + 1] : zero4);
-        dense_flow_x3<B100, T100, false, false>(gp, nullptr, gat, p.x.w_atg, reinterpret_cast<const float4 *>(p.f.b_ata), F, lane, d_ata);
+        dense_flow_x3<B100, T100, false, false>(gp, nullptr, gat, no4, p.x.w_atg, reinterpret_cast<const float4 *>(p.f.b_ata), F, lane, d_ata);
+        if (kX3GatMem) {
+            // parked in the workspace: the per-human attention.0 layers fetch it tile by tile as their accumulator start
+            // (28 registers that would otherwise be live across the whole second pass)
+#pragma unroll
+            for (int t = 0; t < T100; ++t) ws[(N * WSR + t) * 64 + lane] = make_float4(gat[t][0], gat[t][1], gat[t][2], gat[t][3]);
+        }
     } else {
     SARL_LAYER(T100, T100, false, false, 1, 4, gsum, nullptr, gat, p.f.w_atg, p.f.b_ata, d_ata);
     }
@@ -356,16 +381,15 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
             X3 hp[B100];
             load_pieces(hp);
             SARL_PHASE(6);              // workspace load
-            dense_flow_x3<B100, T100, true, true>(hp, gat, a1, p.x.w_ata, nullptr, F, lane, d_atb);
+            X3 ap[B100], bp[B100];
+            dense_flow_x3<B100, T100, true, true, kX3In, kX3GatMem>(hp, kX3GatMem ? reinterpret_cast<const f32x4 *>(ws + (N * WSR) * 64 + lane) : gat,
+                                                                    a1, ap, p.x.w_ata, nullptr, F, lane, d_atb);
+            if (!kX3In) split_after(a1, ap);
             SARL_PHASE(7);              // attention.0
-            X3 ap[B100];
-#pragma unroll
-            for (int m = 0; m < B100; ++m) ap[m] = split8(a1[2 * m], 2 * m + 1 < T100 ? a1[2 * m + 1] : zero4);
-            dense_flow_x3<B100, T100, true, false>(ap, nullptr, a2, p.x.w_atb, reinterpret_cast<const float4 *>(p.f.b_atb), F, lane, d_atc);
+            dense_flow_x3<B100, T100, true, false, kX3In>(ap, nullptr, a2, bp, p.x.w_atb, reinterpret_cast<const float4 *>(p.f.b_atb), F, lane, d_atc);
+            if (!kX3In) split_after(a2, bp);
             SARL_PHASE(8);              // attention.2
-#pragma unroll
-            for (int m = 0; m < B100; ++m) ap[m] = split8(a2[2 * m], 2 * m + 1 < T100 ? a2[2 * m + 1] : zero4);
-            dense_flow_x3<B100, T1, false, false>(ap, nullptr, sc, p.x.w_atc, reinterpret_cast<const float4 *>(p.f.b_atc), F, lane, d_m2a);
+            dense_flow_x3<B100, T1, false, false>(bp, nullptr, sc, no1, p.x.w_atc, reinterpret_cast<const float4 *>(p.f.b_atc), F, lane, d_m2a);
         } else {
 #pragma unroll
         for (int t = 0; t < T100; ++t) {
@@ -390,16 +414,22 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
         if constexpr (USE_X3) {
             X3 hp[B100];
             load_pieces(hp);            // (read again rather than kept: 48 registers across the attention layers)
-            dense_flow_x3<B100, T100, true, false>(hp, nullptr, m1, p.x.w_m2a, reinterpret_cast<const float4 *>(p.f.b_m2a), F, lane,
-                                                  (i + 1 < N ? d_ata : d_m2b));
+            auto pool = [&](int n, const f32x4 &v) {        // weighted sum of the hidden activations, tile by tile
+#pragma unroll
+                for (int r = 0; r < 4; ++r) racc[n][r] = i < ne ? __builtin_fmaf(es, v[r], racc[n][r]) : racc[n][r];
+            };
+            dense_flow_x3<B100, T100, true, false, false, false>(hp, nullptr, m1, no4, p.x.w_m2a, reinterpret_cast<const float4 *>(p.f.b_m2a),
+                                                                F, lane, (i + 1 < N ? d_ata : d_m2b), pool);
         } else {
         SARL_LAYER(T100, T100, true, false, 1, 4, h2, nullptr, m1, p.f.w_m2a, p.f.b_m2a, (i + 1 < N ? d_ata : d_m2b));
         }
         SARL_PHASE(11);                 // mlp2.0
+        if constexpr (!USE_X3) {
 #pragma unroll
         for (int t = 0; t < T100; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) racc[t][r] = i < ne ? __builtin_fmaf(es, m1[t][r], racc[t][r]) : racc[t][r];
+        }
         SARL_PHASE(12);                 // weighted accumulation
     }
 
@@ -417,7 +447,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
             X3 rp3[B100];
 #pragma unroll
             for (int m = 0; m < B100; ++m) rp3[m] = split8(racc[2 * m], 2 * m + 1 < T100 ? racc[2 * m + 1] : zero4);
-            dense_flow_x3<B100, T50, false, false>(rp3, nullptr, pooled, p.x.w_m2b, reinterpret_cast<const float4 *>(p.f.b_m2b), F, lane, d_m3a);
+            dense_flow_x3<B100, T50, false, false>(rp3, nullptr, pooled, no2, p.x.w_m2b, reinterpret_cast<const float4 *>(p.f.b_m2b), F, lane, d_m3a);
         } else {
         SARL_LAYER(T100, T50, false, false, 1, 4, racc, nullptr, pooled, p.f.w_m2b, p.f.b_m2b, d_m3a);
         }
@@ -438,18 +468,15 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
     if constexpr (USE_X3) {
         X3 jp[B56];                     // input blocks: (pooled tiles 0, 1), (pooled tiles 2, 3), (self tile, -)
         jp[0] = split8(jin[0], jin[1]); jp[1] = split8(jin[2], jin[3]); jp[2] = split8(jin[4], zero4);
-        dense_flow_x3<B56, T150, true, false>(jp, nullptr, v1, p.x.w_m3a, reinterpret_cast<const float4 *>(p.f.b_m3a), F, lane, d_m3b);
         X3 vp[B150];
-#pragma unroll
-        for (int m = 0; m < B150; ++m) vp[m] = split8(v1[2 * m], v1[2 * m + 1]);
-        dense_flow_x3<B150, T100, true, false>(vp, nullptr, v2, p.x.w_m3b, reinterpret_cast<const float4 *>(p.f.b_m3b), F, lane, d_m3c);
-        X3 wp[B100];
-#pragma unroll
-        for (int m = 0; m < B100; ++m) wp[m] = split8(v2[2 * m], 2 * m + 1 < T100 ? v2[2 * m + 1] : zero4);
-        dense_flow_x3<B100, T100, true, false>(wp, nullptr, v3, p.x.w_m3c, reinterpret_cast<const float4 *>(p.f.b_m3c), F, lane, d_m3d);
-#pragma unroll
-        for (int m = 0; m < B100; ++m) wp[m] = split8(v3[2 * m], 2 * m + 1 < T100 ? v3[2 * m + 1] : zero4);
-        dense_flow_x3<B100, T1, false, false>(wp, nullptr, vo, p.x.w_m3d, reinterpret_cast<const float4 *>(p.f.b_m3d), F, lane,
+        dense_flow_x3<B56, T150, true, false, kX3In>(jp, nullptr, v1, vp, p.x.w_m3a, reinterpret_cast<const float4 *>(p.f.b_m3a), F, lane, d_m3b);
+        if (!kX3In) split_after(v1, vp);
+        X3 wp[B100], xp[B100];
+        dense_flow_x3<B150, T100, true, false, kX3In>(vp, nullptr, v2, wp, p.x.w_m3b, reinterpret_cast<const float4 *>(p.f.b_m3b), F, lane, d_m3c);
+        if (!kX3In) split_after(v2, wp);
+        dense_flow_x3<B100, T100, true, false, kX3In>(wp, nullptr, v3, xp, p.x.w_m3c, reinterpret_cast<const float4 *>(p.f.b_m3c), F, lane, d_m3d);
+        if (!kX3In) split_after(v3, xp);
+        dense_flow_x3<B100, T1, false, false>(xp, nullptr, vo, no1, p.x.w_m3d, reinterpret_cast<const float4 *>(p.f.b_m3d), F, lane,
                                              (grp + gridDim.x < p.ngroups ? d_m1a : d_none));
     } else {
     SARL_LAYER(T56, T150, true, false, 2, 1, jin, nullptr, v1, p.f.w_m3a, p.f.b_m3a, d_m3b);
@@ -576,7 +603,7 @@ long sarl_workspace_float4s(int E, int N, int A)
     const long waves = ((long)E * A + 15) / 16;
     long groups = (waves + kSarlWaves - 1) / kSarlWaves;
     if (groups > kSarlMaxBlocks) groups = kSarlMaxBlocks;          // one slot per RESIDENT wavefront
-    return groups * kSarlWaves * (long)N * (kWsRowsX3 > kWsRowsF32 ? kWsRowsX3 : kWsRowsF32) * 64;
+    return groups * kSarlWaves * ((long)N * kWsRowsX3 + T100) * 64;           // per wavefront: N humans x 12 rows + 7 (x3 layout)
 }
 
 }  // namespace mcn

@@ -381,3 +381,34 @@ def test_per_env_pedestrian_counts():
     np.testing.assert_allclose(v3[e], pyref.sarl_predict(w, row, hum, table)[0], rtol=0, atol=TOL)
     with pytest.raises(ValueError):
         pol.predict_batch(env, hcount=hc.long())
+
+
+@pytest.mark.parametrize("N", [5, 10, 3])
+def test_bf16x3_layers_agree_with_the_float32_mfma_layers(N):
+    """The look-ahead's layers run on the bf16 matrix pipe with every float32 operand split into three bfloat16 pieces
+    (mcn_sarl_net.x3, csrc/mfma_chain.hpp: dense_flow_x3); mcn_tuning.sarl_x3 = 0 keeps the float32 MFMA layers.  Both
+    are float32-accurate evaluations of the same network: on the same 1 024-env batch they agree to a few float32
+    rounding steps of the values (|v| ~ 1: 3e-6), far inside the 1e-5 parity bar each holds against the reference, and
+    the rewards -- float64, computed outside the network -- are identical."""
+    import torch
+    from modelcrowdnav_amd import _hip
+    rng = np.random.RandomState(70 + N)
+    E = 1024
+    pol = _policy(seed=5)
+    env = H.make_vec_env(E, N)
+    H.upload(env, H.random_state(rng, E, N, randomize=True))
+    assert _hip.get_tuning().sarl_x3 != 0
+    _, best_x3, v_x3 = pol.predict_batch(env, want_values=True)
+    v_x3, best_x3 = v_x3.clone(), best_x3.clone()
+    with _hip.tuned(sarl_x3=0):
+        _, best_f32, v_f32 = pol.predict_batch(env, want_values=True)
+        v_f32, best_f32 = v_f32.clone(), best_f32.clone()
+    torch.cuda.synchronize()
+    d = (v_x3 - v_f32).abs().max().item()
+    assert d <= 3e-6, d
+    assert d > 0.0, "the two paths should not be the same kernel"
+    same = (best_x3 == best_f32)
+    # a different argmax needs two candidate values closer than the two paths' own difference
+    top2 = torch.topk(v_f32, 2, dim=1).values
+    assert bool((same | ((top2[:, 0] - top2[:, 1]) < 2 * d)).all())
+    assert same.float().mean().item() > 0.99

@@ -157,10 +157,11 @@ def sarl_bench(E=4096, N=5, iters=5):
         pol.predict_batch(env)
     e.record(); torch.cuda.synchronize()
     ms = s.elapsed_time(e) / iters
-    flop = 81 * (N * 124100 + 67000) * E
-    ex = (E * 81 + 15) // 16 * bench.sarl_mfma_per_tile(N) * 2048
-    print("SARL lookahead N=%d E=%d: %.3f ms/launch  %.1f TFLOP/s executed = %.3f of the fp32 MFMA peak 157.3 (%.1f by the reference's FLOP count)  %.3f M env-steps/s" % (
-        N, E, ms, ex / ms / 1e9, ex / ms / 1e9 / 157.3, flop / ms / 1e9, E / ms / 1e3))
+    r = bench._sarl_roofline(E, N, ms)
+    print("SARL lookahead N=%d E=%d: %.3f ms/launch  %.1f TFLOP/s executed = %.3f of the %.1f peak [%s]; float32-MFMA "
+          "equivalent %.1f TFLOP/s = %.3f of the fp32 MFMA peak 157.3 (%.1f by the reference's FLOP count)  %.3f M env-steps/s" % (
+              N, E, ms, r["achieved"], r["frac"], r["peak"], "bf16x3" if bench.sarl_uses_x3() else "f32", r["f32_mfma_equivalent_rate"],
+              r["f32_mfma_equivalent_rate_over_f32_peak"], r["reference_flop_rate"], E / ms / 1e3))
     s.record()
     for _ in range(iters):
         a, b = pol.predict_batch(env)

@@ -603,17 +603,33 @@ __device__ __forceinline__ NextChunk first_chunk_x3(const float4 *wf, const floa
 // second-to-last group of a chunk (every read of the chunk has been issued by then).
 // init: accumulator start when HAS_INIT -- a register array, or (INIT_MEM) this lane's column of a [NT][64] float4 table
 // in global memory (`init` then points at element [0][lane]; tile n + 1's row is fetched while tile n is multiplied).
-// chunk geometry of an x3 layer in GROUPS (output tile, input block): first / last group of chunk c, and the group before
-// whose MFMAs that chunk's barrier sits (MCN_X3_AHEAD - 1 groups before its last: every read of the chunk issued by then)
+// chunk geometry of an x3 layer.  A UNIT is one (output tile, input block): three A pieces, six MFMAs, 96 pipe cycles.
+// A GROUP is up to MCN_X3_UNITS consecutive units of one chunk; the A pieces of group G + 1 are requested behind the first
+// MFMA of group G, so a group's length is the cover its successor's LDS reads get.  (While an LDS-DMA is in flight every
+// LDS wait the compiler emits is lgkmcnt(0): "request further ahead" does not lengthen the cover -- the wait of group G
+// drains the reads of G + 1 as well -- longer groups do.)  Measured at 4096 x 5 (same box, diagnostic builds): 1 unit
+// 1.62-1.63 ms per step, 2 units 1.64, 3 units 1.66-1.69: the LDS round trip is not what the layers wait for, and the
+// longer ring costs registers.  Default 1.
+#ifndef MCN_X3_UNITS
+#define MCN_X3_UNITS 1
+#endif
 template <int KB, int NT>
 struct X3Geo {
+    static constexpr int U = MCN_X3_UNITS;
     static constexpr int CT = x3_chunk_tiles(KB, NT);
-    static constexpr int chunk_of(int g) { return (g / KB) / CT; }
-    static constexpr int first_of(int c) { return c * CT * KB; }
-    static constexpr int last_of(int c) { return ((c + 1) * CT < NT ? (c + 1) * CT : NT) * KB - 1; }
-    static constexpr int barrier_at(int c)
+    static constexpr int NCH = x3_chunks(KB, NT);
+    static constexpr int UC = CT * KB;                                   // units of a full chunk
+    static constexpr int GPC = (UC + U - 1) / U;                         // groups of a full chunk
+    static constexpr int units_in(int c) { return ((c + 1) * CT < NT ? CT : NT - c * CT) * KB; }
+    static constexpr int groups_in(int c) { return (units_in(c) + U - 1) / U; }
+    static constexpr int NG = (NCH - 1) * GPC + groups_in(NCH - 1);
+    static constexpr int chunk_of(int g) { return g / GPC < NCH ? g / GPC : NCH - 1; }
+    static constexpr int first_of(int c) { return c * GPC; }
+    static constexpr int last_of(int c) { return c * GPC + groups_in(c) - 1; }
+    static constexpr int unit0(int g) { return chunk_of(g) * UC + (g - first_of(chunk_of(g))) * U; }
+    static constexpr int count(int g)
     {
-        return last_of(c) - (MCN_X3_AHEAD - 1) > first_of(c) ? last_of(c) - (MCN_X3_AHEAD - 1) : first_of(c);
+        return units_in(chunk_of(g)) - (g - first_of(chunk_of(g))) * U < U ? units_in(chunk_of(g)) - (g - first_of(chunk_of(g))) * U : U;
     }
 };
 template <class Fn, int... Gs>
@@ -641,7 +657,6 @@ __device__ __forceinline__ void dense_flow_x3(const X3 (&in)[KB], const f32x4 *i
     constexpr int BCH = CT * 64;
     constexpr int BPER = (BCH + kStageThreads - 1) / kStageThreads;
     static_assert(BOFF + (HAS_INIT ? 0 : BCH) <= kStageFloat4 + kStageBias, "x3 chunk + biases do not fit the LDS stage");
-    static_assert(KB * CT >= 2 || NT * KB == 1, "a staged chunk holds at least two groups");
     float4 *const bufp[2] = {F.buf + F.parity * kStageBuf, F.buf + (F.parity ^ 1) * kStageBuf};
     auto stage = [&](int c) {                             // chunk c >= 1 of THIS layer -> buffer (parity + c) & 1
         int tid_ = F.tid;
@@ -667,76 +682,85 @@ __device__ __forceinline__ void dense_flow_x3(const X3 (&in)[KB], const f32x4 *i
             }
         }
     };
-    constexpr int NG = NT * KB;                           // groups: (output tile, input block), six MFMAs each
-    constexpr int AHEAD = MCN_X3_AHEAD, RING = AHEAD + 1; // groups the A pieces are requested ahead of their use
-    float4 ra[RING][3], bias[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    using Geo = X3Geo<KB, NT>;
+    constexpr int NG = Geo::NG, U = Geo::U;
+    float4 ra[2][U][3], bias[4] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
     // (The group loop is a compile-time expansion -- static_for over integral constants -- not an unrolled run-time loop:
     //  every array index is a constant from the start, so the register promotion of the operand arrays does not depend
     //  on when the optimiser gets round to unrolling ~50 groups; as a `for` loop the output pieces ended up in scratch.)
-    auto issue = [&](auto gc) {
+    auto issue = [&](auto gc) {                           // LDS -> ring slot g & 1: the A pieces of the group's units
         constexpr int g = decltype(gc)::value;
-        constexpr int n = g / KB, m = g - n * KB;
-        constexpr int c = n / CT, h = n - c * CT;
-        const float4 *w = bufp[c & 1] + (h * KB + m) * 192;
-        ra[g % RING][0] = w[lane]; ra[g % RING][1] = w[64 + lane]; ra[g % RING][2] = w[128 + lane];
-        if (m == 0 && !HAS_INIT) bias[n & 1] = bufp[c & 1][BOFF + h * 64 + lane];
+        constexpr int c = Geo::chunk_of(g);
+        static_for([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k < Geo::count(g)) {
+                constexpr int u = Geo::unit0(g) + k, n = u / KB, m = u - n * KB, h = n - c * CT;
+                const float4 *w = bufp[c & 1] + (h * KB + m) * 192;
+                ra[g & 1][k][0] = w[lane]; ra[g & 1][k][1] = w[64 + lane]; ra[g & 1][k][2] = w[128 + lane];
+                if (m == 0 && !HAS_INIT) bias[n & 3] = bufp[c & 1][BOFF + h * 64 + lane];
+            }
+        }, std::make_integer_sequence<int, U>{});
     };
     auto request_next = [&](int c) {                      // what follows chunk c: this layer's next chunk, or the next layer's first
         if (c + 1 < NCH) stage(c + 1);
         else if (next.n_w > 0) flow_stage_first(F, next, (F.parity + NCH) & 1);
     };
     issue(std::integral_constant<int, 0>{});
-    if constexpr (AHEAD > 1 && NG > 1 && X3Geo<KB, NT>::chunk_of(1) == 0) issue(std::integral_constant<int, 1>{});
     f32x4 a = {0, 0, 0, 0};
     float4 initv[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
     if (HAS_INIT && INIT_MEM) initv[0] = reinterpret_cast<const float4 *>(init)[0];
     auto group = [&](auto gc) {
         constexpr int g = decltype(gc)::value;
-        using Geo = X3Geo<KB, NT>;
-        constexpr int n = g / KB, m = g - n * KB;
         constexpr int c = Geo::chunk_of(g);
-        constexpr bool at_first = g == Geo::first_of(c), at_barrier = g == Geo::barrier_at(c);
-        if constexpr (at_barrier) {
+        constexpr bool at_first = g == Geo::first_of(c), at_last = g == Geo::last_of(c);
+        if constexpr (at_last) {
             if constexpr (at_first) request_next(c);      // (the request must precede the barrier that publishes it)
             __syncthreads();                              // every read of chunk c has been issued and is back; DMAs landed
         }
-        if constexpr (m == 0) {
-            if constexpr (HAS_INIT && INIT_MEM) {
-                a = (f32x4){initv[n & 1].x, initv[n & 1].y, initv[n & 1].z, initv[n & 1].w};
-                if constexpr (n + 1 < NT) initv[(n + 1) & 1] = reinterpret_cast<const float4 *>(init)[(n + 1) * 64];
-            } else if constexpr (HAS_INIT) a = init[n];
-            else a = (f32x4){bias[n & 1].x, bias[n & 1].y, bias[n & 1].z, bias[n & 1].w};
-        }
-        const bf16x8 wh = __builtin_bit_cast(bf16x8, ra[g % RING][0]), wm = __builtin_bit_cast(bf16x8, ra[g % RING][1]),
-                     wl = __builtin_bit_cast(bf16x8, ra[g % RING][2]);
-        __builtin_amdgcn_sched_barrier(MCN_X3_FENCE);              // vector / scalar ALU work may move across, nothing else
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, in[m].hi, a, 0, 0, 0);            // smallest terms first
-        __builtin_amdgcn_sched_barrier(MCN_X3_FENCE);
-        // AHEAD groups ahead -- but never into a chunk whose barrier has not been passed
-        if constexpr (g + AHEAD < NG) {
-            if constexpr (Geo::chunk_of(g + AHEAD) == c || g >= Geo::barrier_at(c)) issue(std::integral_constant<int, g + AHEAD>{});
-        }
-        if constexpr (at_first && !at_barrier) request_next(c);
-        __builtin_amdgcn_sched_barrier(MCN_X3_FENCE);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, in[m].lo, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, in[m].mid, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, in[m].hi, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, in[m].mid, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, in[m].hi, a, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(MCN_X3_FENCE);
-        if constexpr (m == KB - 1) {
-            if (RELU) {
+        static_for([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k < Geo::count(g)) {
+                constexpr int u = Geo::unit0(g) + k, n = u / KB, m = u - n * KB;
+                if constexpr (m == 0) {
+                    if constexpr (HAS_INIT && INIT_MEM) {
+                        a = (f32x4){initv[n & 1].x, initv[n & 1].y, initv[n & 1].z, initv[n & 1].w};
+                        if constexpr (n + 1 < NT) initv[(n + 1) & 1] = reinterpret_cast<const float4 *>(init)[(n + 1) * 64];
+                    } else if constexpr (HAS_INIT) a = init[n];
+                    else a = (f32x4){bias[n & 3].x, bias[n & 3].y, bias[n & 3].z, bias[n & 3].w};
+                }
+                const bf16x8 wh = __builtin_bit_cast(bf16x8, ra[g & 1][k][0]), wm = __builtin_bit_cast(bf16x8, ra[g & 1][k][1]),
+                             wl = __builtin_bit_cast(bf16x8, ra[g & 1][k][2]);
+                __builtin_amdgcn_sched_barrier(MCN_X3_FENCE);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, in[m].hi, a, 0, 0, 0);    // smallest terms first
+                if constexpr (k == 0) {
+                    // behind the group's FIRST MFMA (whose wait for this group's pieces must not see them yet): the next
+                    // group's reads, and at a chunk's first group the DMA of what follows the chunk
+                    __builtin_amdgcn_sched_barrier(MCN_X3_FENCE);
+                    if constexpr (g + 1 < NG) issue(std::integral_constant<int, g + 1>{});
+                    if constexpr (at_first && !at_last) request_next(c);
+                    __builtin_amdgcn_sched_barrier(MCN_X3_FENCE);
+                }
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, in[m].lo, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, in[m].mid, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, in[m].hi, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, in[m].mid, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, in[m].hi, a, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(MCN_X3_FENCE);
+                if constexpr (m == KB - 1) {
+                    if (RELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a[r] = relu_f32(a[r]);
+                        for (int r = 0; r < 4; ++r) a[r] = relu_f32(a[r]);
+                    }
+                    out[n] = a;
+                    on_tile(n, a);
+                    if constexpr (SPLIT && ((n & 1) || n == NT - 1)) {
+                        const f32x4 z = {0, 0, 0, 0};
+                        if constexpr (n & 1) outp[n >> 1] = split8(out[n - 1], out[n]);
+                        else outp[n >> 1] = split8(out[n], z);
+                    }
+                }
             }
-            out[n] = a;
-            on_tile(n, a);
-            if constexpr (SPLIT && ((n & 1) || n == NT - 1)) {
-                const f32x4 z = {0, 0, 0, 0};
-                if constexpr (n & 1) outp[n >> 1] = split8(out[n - 1], out[n]);
-                else outp[n >> 1] = split8(out[n], z);
-            }
-        }
+        }, std::make_integer_sequence<int, U>{});
     };
     static_for(group, std::make_integer_sequence<int, NG>{});
     F.parity = (F.parity + NCH) & 1;

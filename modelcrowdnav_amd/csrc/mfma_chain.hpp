@@ -388,13 +388,59 @@ struct WeightFlow {
 };
 constexpr int kStageBuf = kStageFloat4 + kStageBias;
 
+#ifndef MCN_LEAN_DMA
+#define MCN_LEAN_DMA 1
+#endif
+// One workgroup-wide LDS-DMA of `n` float4 rows src[0 .. n) to dst[0 .. n) in rounds of kStageThreads rows (round 4).
+// The what-if builds (profiles/r04_sarl_x3_whatif.txt) showed ISSUING the weight stream -- ~750 global_load_lds per
+// wavefront and tile, each with a 64-bit vector address, a clamp, a readfirstlane and an M0 move -- to cost as much as
+// the splitting and the barriers together.  Here an instruction is SGPR base + one 32-bit VGPR offset (the saddr form:
+// one v_add instead of a 64-bit address), no round past the end of the rows, a clamp only in the round that straddles
+// it: 5 instructions per DMA instead of 10.  `n` and the round loop fold
+// at compile time at every call site.
+struct DmaLane {
+    unsigned off;     // this thread's byte offset inside a round: tid * 16 (VGPR)
+    int wave_base;    // tid & ~63 (left in a VGPR: read into an SGPR once, the per-round M0 values were hoisted as scalars
+                      // and spilled -- 569 VGPR spills)
+};
+__device__ __forceinline__ DmaLane dma_lane(int tid)
+{
+    int t = tid;
+    asm volatile("" : "+v"(t));                            // (a hoisted copy per call site costs a VGPR each)
+    return {static_cast<unsigned>(t) * 16u, t & ~63};
+}
+template <int MAX_ROUNDS>
+__device__ __forceinline__ void dma_rows(const float4 *base, int first, int n, float4 *dst, const DmaLane &L)
+{
+    // rows base[first .. first + n); the row offset goes into the VGPR offset (one v_add per instruction, wrapping
+    // unsigned so that it cannot be split off again): a scalar base per round would cost an SGPR pair per round and
+    // layer -- 541 spilled SGPRs when tried
+#pragma unroll
+    for (int k = 0; k < MAX_ROUNDS; ++k) {
+        const int left = n - k * kStageThreads;            // rows from this round's first to the end
+        if (left > 0) {                                    // wave-uniform (compile-time at the call sites)
+            unsigned off = L.off;
+            if (left < kStageThreads) off = off < (left - 1) * 16u ? off : (left - 1) * 16u;
+            off += static_cast<unsigned>(first + k * kStageThreads) * 16u;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(base) + off),
+                (__attribute__((address_space(3))) void *)(dst + k * kStageThreads + L.wave_base), 16, 0, 0);
+        }
+    }
+}
+
 // DMA of a layer's chunk 0 into stage buffer `b` (0 / 1, run-time); every thread of the workgroup calls it.
 __device__ __forceinline__ void flow_stage_first(const WeightFlow &F, const NextChunk &d, int b)
 {
+    float4 *dst = F.buf + b * kStageBuf;
+#if MCN_LEAN_DMA
+    const DmaLane L = dma_lane(F.tid);
+    dma_rows<kStageFloat4 / kStageThreads>(d.w, 0, d.n_w, dst, L);
+    dma_rows<3>(d.b, 0, d.n_b, dst + d.b_at, L);              // up to 12 bias tiles
+#else
     int tid_ = F.tid;
     asm volatile("" : "+v"(tid_));
     const int wave_base = tid_ & ~63;
-    float4 *dst = F.buf + b * kStageBuf;
 #pragma unroll
     for (int k = 0; k < kStageFloat4 / kStageThreads; ++k) {
         if (k * kStageThreads < d.n_w) {                                   // wave-uniform
@@ -415,6 +461,7 @@ __device__ __forceinline__ void flow_stage_first(const WeightFlow &F, const Next
                                              16, 0, 0);
         }
     }
+#endif
 }
 
 // Precondition: chunk 0 of this layer has been requested into buffer F.parity AND a workgroup barrier (with vmcnt(0))
@@ -558,6 +605,10 @@ struct X3 { bf16x8 hi, mid, lo; };
 __device__ __forceinline__ X3 split8(const f32x4 a, const f32x4 b)
 {
     X3 s;
+#if MCN_X3_WHATIF & 16
+    s.hi = __builtin_bit_cast(bf16x8, a); s.mid = __builtin_bit_cast(bf16x8, b); s.lo = s.hi;
+    return s;
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const float x = i < 4 ? a[i] : b[i - 4];
@@ -593,6 +644,11 @@ __device__ __forceinline__ NextChunk first_chunk_x3(const float4 *wf, const floa
                      x3_bias_at(KB, NT)};
 }
 
+#if MCN_X3_WHATIF & 8
+#define X3_MFMA(wa, xb, acc, c0, c1, c2) (acc)
+#else
+#define X3_MFMA(wa, xb, acc, c0, c1, c2) __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc, c0, c1, c2)
+#endif
 // One layer: in = KB input blocks of 32 features (split), out = NT output tiles of 16 features (float32 accumulators,
 // bias / init added, ReLU applied); SPLIT: also outp = the ceil(NT / 2) input blocks of the layer that follows, each
 // split as soon as its two tiles are finished, so that the splitting's vector instructions run in the shadow of the
@@ -612,6 +668,12 @@ __device__ __forceinline__ NextChunk first_chunk_x3(const float4 *wf, const floa
 // longer ring costs registers.  Default 1.
 #ifndef MCN_X3_UNITS
 #define MCN_X3_UNITS 1
+#endif
+// TIMING-ONLY what-if builds (wrong values; tools/ab_build.sh + kbench): bit 0 no workgroup barriers, bit 1 no weight DMA,
+// bit 2 no LDS reads of the A pieces (after the first group), bit 3 no MFMAs, bit 4 no splitting (split8 returns its input
+// bits), bit 5 no workspace traffic between the passes.  0 in every product build.
+#ifndef MCN_X3_WHATIF
+#define MCN_X3_WHATIF 0
 #endif
 template <int KB, int NT>
 struct X3Geo {
@@ -659,27 +721,13 @@ __device__ __forceinline__ void dense_flow_x3(const X3 (&in)[KB], const f32x4 *i
     static_assert(BOFF + (HAS_INIT ? 0 : BCH) <= kStageFloat4 + kStageBias, "x3 chunk + biases do not fit the LDS stage");
     float4 *const bufp[2] = {F.buf + F.parity * kStageBuf, F.buf + (F.parity ^ 1) * kStageBuf};
     auto stage = [&](int c) {                             // chunk c >= 1 of THIS layer -> buffer (parity + c) & 1
-        int tid_ = F.tid;
-        asm volatile("" : "+v"(tid_));
-        const int wave_base = tid_ & ~63;
         float4 *dst = bufp[c & 1];
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            int i = c * CH + tid_ + k * kStageThreads;
-            i = i < TOTAL - 1 ? i : TOTAL - 1;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wf + i),
-                                             (__attribute__((address_space(3))) void *)(dst + k * kStageThreads + wave_base),
-                                             16, 0, 0);
-        }
+        const DmaLane L = dma_lane(F.tid);
+        const int rows = TOTAL - c * CH < CH ? TOTAL - c * CH : CH;
+        dma_rows<PER>(wf, c * CH, rows, dst, L);
         if (!HAS_INIT) {
-#pragma unroll
-            for (int k = 0; k < BPER; ++k) {
-                int i = c * BCH + tid_ + k * kStageThreads;
-                i = i < NT * 64 - 1 ? i : NT * 64 - 1;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bf + i),
-                                                 (__attribute__((address_space(3))) void *)(dst + BOFF + k * kStageThreads + wave_base),
-                                                 16, 0, 0);
-            }
+            const int brows = NT * 64 - c * BCH < BCH ? NT * 64 - c * BCH : BCH;
+            dma_rows<BPER>(bf, c * BCH, brows, dst + BOFF, L);
         }
     };
     using Geo = X3Geo<KB, NT>;
@@ -702,6 +750,7 @@ __device__ __forceinline__ void dense_flow_x3(const X3 (&in)[KB], const f32x4 *i
         }, std::make_integer_sequence<int, U>{});
     };
     auto request_next = [&](int c) {                      // what follows chunk c: this layer's next chunk, or the next layer's first
+        if (MCN_X3_WHATIF & 2) return;
         if (c + 1 < NCH) stage(c + 1);
         else if (next.n_w > 0) flow_stage_first(F, next, (F.parity + NCH) & 1);
     };
@@ -715,7 +764,7 @@ __device__ __forceinline__ void dense_flow_x3(const X3 (&in)[KB], const f32x4 *i
         constexpr bool at_first = g == Geo::first_of(c), at_last = g == Geo::last_of(c);
         if constexpr (at_last) {
             if constexpr (at_first) request_next(c);      // (the request must precede the barrier that publishes it)
-            __syncthreads();                              // every read of chunk c has been issued and is back; DMAs landed
+            if (!(MCN_X3_WHATIF & 1)) __syncthreads();    // every read of chunk c has been issued and is back; DMAs landed
         }
         static_for([&](auto kc) {
             constexpr int k = decltype(kc)::value;
@@ -731,20 +780,20 @@ __device__ __forceinline__ void dense_flow_x3(const X3 (&in)[KB], const f32x4 *i
                 const bf16x8 wh = __builtin_bit_cast(bf16x8, ra[g & 1][k][0]), wm = __builtin_bit_cast(bf16x8, ra[g & 1][k][1]),
                              wl = __builtin_bit_cast(bf16x8, ra[g & 1][k][2]);
                 __builtin_amdgcn_sched_barrier(MCN_X3_FENCE);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, in[m].hi, a, 0, 0, 0);    // smallest terms first
+                a = X3_MFMA(wl, in[m].hi, a, 0, 0, 0);    // smallest terms first
                 if constexpr (k == 0) {
                     // behind the group's FIRST MFMA (whose wait for this group's pieces must not see them yet): the next
                     // group's reads, and at a chunk's first group the DMA of what follows the chunk
                     __builtin_amdgcn_sched_barrier(MCN_X3_FENCE);
-                    if constexpr (g + 1 < NG) issue(std::integral_constant<int, g + 1>{});
+                    if constexpr (g + 1 < NG) { if (!(MCN_X3_WHATIF & 4)) issue(std::integral_constant<int, g + 1>{}); }
                     if constexpr (at_first && !at_last) request_next(c);
                     __builtin_amdgcn_sched_barrier(MCN_X3_FENCE);
                 }
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, in[m].lo, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, in[m].mid, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, in[m].hi, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, in[m].mid, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, in[m].hi, a, 0, 0, 0);
+                a = X3_MFMA(wh, in[m].lo, a, 0, 0, 0);
+                a = X3_MFMA(wm, in[m].mid, a, 0, 0, 0);
+                a = X3_MFMA(wm, in[m].hi, a, 0, 0, 0);
+                a = X3_MFMA(wh, in[m].mid, a, 0, 0, 0);
+                a = X3_MFMA(wh, in[m].hi, a, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(MCN_X3_FENCE);
                 if constexpr (m == KB - 1) {
                     if (RELU) {

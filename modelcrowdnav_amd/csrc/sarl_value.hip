@@ -298,6 +298,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
             // the workspace keeps mlp1's output already split: pass 2 reads the pieces twice (attention.0, mlp2.0)
 #pragma unroll
             for (int m = 0; m < B100; ++m) {
+                if (MCN_X3_WHATIF & 32) break;
                 ws[(i * WSR + 3 * m + 0) * 64 + lane] = __builtin_bit_cast(float4, h2p[m].hi);
                 ws[(i * WSR + 3 * m + 1) * 64 + lane] = __builtin_bit_cast(float4, h2p[m].mid);
                 ws[(i * WSR + 3 * m + 2) * 64 + lane] = __builtin_bit_cast(float4, h2p[m].lo);
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
         auto load_pieces = [&](X3 (&dst)[B100]) {          // mlp1's output of human i, as pass 1 split it
 #pragma unroll
             for (int m = 0; m < B100; ++m) {
+                if (MCN_X3_WHATIF & 32) { dst[m].hi = dst[m].mid = dst[m].lo = __builtin_bit_cast(bf16x8, make_float4(1.f, 2.f, 3.f, (float)i)); continue; }
                 dst[m].hi = __builtin_bit_cast(bf16x8, ws[(i * WSR + 3 * m + 0) * 64 + lane]);
                 dst[m].mid = __builtin_bit_cast(bf16x8, ws[(i * WSR + 3 * m + 1) * 64 + lane]);
                 dst[m].lo = __builtin_bit_cast(bf16x8, ws[(i * WSR + 3 * m + 2) * 64 + lane]);

@@ -388,6 +388,9 @@ struct WeightFlow {
 };
 constexpr int kStageBuf = kStageFloat4 + kStageBias;
 
+#ifndef MCN_X3_WHATIF
+#define MCN_X3_WHATIF 0     // timing-only what-if bits (profiles/r04_sarl_x3_whatif.txt); any non-zero value computes garbage
+#endif
 #ifndef MCN_LEAN_DMA
 #define MCN_LEAN_DMA 1
 #endif
@@ -424,7 +427,7 @@ __device__ __forceinline__ void dma_rows(const float4 *base, int first, int n, f
             off += static_cast<unsigned>(first + k * kStageThreads) * 16u;
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(base) + off),
-                (__attribute__((address_space(3))) void *)(dst + k * kStageThreads + L.wave_base), 16, 0, 0);
+                (__attribute__((address_space(3))) void *)(dst + k * kStageThreads + L.wave_base), (MCN_X3_WHATIF & 128) ? 4 : 16, 0, 0);
         }
     }
 }
@@ -672,9 +675,6 @@ __device__ __forceinline__ NextChunk first_chunk_x3(const float4 *wf, const floa
 // TIMING-ONLY what-if builds (wrong values; tools/ab_build.sh + kbench): bit 0 no workgroup barriers, bit 1 no weight DMA,
 // bit 2 no LDS reads of the A pieces (after the first group), bit 3 no MFMAs, bit 4 no splitting (split8 returns its input
 // bits), bit 5 no workspace traffic between the passes.  0 in every product build.
-#ifndef MCN_X3_WHATIF
-#define MCN_X3_WHATIF 0
-#endif
 template <int KB, int NT>
 struct X3Geo {
     static constexpr int U = MCN_X3_UNITS;
@@ -744,7 +744,14 @@ __device__ __forceinline__ void dense_flow_x3(const X3 (&in)[KB], const f32x4 *i
             if constexpr (k < Geo::count(g)) {
                 constexpr int u = Geo::unit0(g) + k, n = u / KB, m = u - n * KB, h = n - c * CT;
                 const float4 *w = bufp[c & 1] + (h * KB + m) * 192;
-                ra[g & 1][k][0] = w[lane]; ra[g & 1][k][1] = w[64 + lane]; ra[g & 1][k][2] = w[128 + lane];
+                if (MCN_X3_WHATIF & 64) {                // timing only: the same three reads at half the bytes
+                    const float2 *w2 = reinterpret_cast<const float2 *>(w);
+                    const float2 t0 = w2[lane], t1 = w2[128 + lane], t2 = w2[256 + lane];
+                    ra[g & 1][k][0] = make_float4(t0.x, t0.y, t0.x, t0.y); ra[g & 1][k][1] = make_float4(t1.x, t1.y, t1.x, t1.y);
+                    ra[g & 1][k][2] = make_float4(t2.x, t2.y, t2.x, t2.y);
+                } else {
+                    ra[g & 1][k][0] = w[lane]; ra[g & 1][k][1] = w[64 + lane]; ra[g & 1][k][2] = w[128 + lane];
+                }
                 if (m == 0 && !HAS_INIT) bias[n & 3] = bufp[c & 1][BOFF + h * 64 + lane];
             }
         }, std::make_integer_sequence<int, U>{});

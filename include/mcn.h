@@ -101,10 +101,13 @@ typedef struct mcn_env_out {
                            * and then owned by the env (the kernels keep its header consistent), or NULL.  With a queue,
                            * large ORCA batches of <= 10 humans solve RVO2's rare linearProgram3 in a second, dense launch
                            * (one parked problem per lane) instead of inside the step kernel, where one or two lanes of a
-                           * wavefront would run it while the others wait.  Same results bit for bit. */
+                           * wavefront would run it while the others wait.  Same results bit for bit.  The queue holds
+                           * half of the worst case (0.9-3.7 % of the humans use it in a circle crossing, in bursts):
+                           * humans beyond that are solved inside the step kernel as without a queue. */
 } mcn_env_out;
 
-/* Bytes of mcn_env_out.lp3_queue for E envs of N humans (0 when N is outside the deferred path's range). */
+/* Bytes of mcn_env_out.lp3_queue for E envs of N humans (0 when N is outside the deferred path's range):
+ * 65 KiB of counters + 256 sub-queues x max(64, worst case / 2) entries x (28 + 16 N) bytes -- 264 MB for 2^18 x 10. */
 int64_t mcn_env_lp3_queue_bytes(int32_t E, int32_t N);
 
 /*

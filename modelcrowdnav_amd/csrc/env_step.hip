@@ -236,12 +236,16 @@ __device__ __forceinline__ void env_step_body(const StepParams &p)
                 int nl_ = 0, fail_ = 0;
                 orca_sort_lp2<NC>(Lnat, dd, (float)attr.y, (float)(goal.x - pos.x), (float)(goal.y - pos.y),
                                   c.orca_neighbor_dist, c.orca_max_neighbors, ox, oy, fail_, nl_);
+                bool solve_here = true;
                 if (p.lp3_defer) {
                     // Deferred 3-D LP (lp3_queue.hpp): the few humans whose 2-D LP failed park their problem in the
                     // queue -- one atomic per wavefront, consecutive slots for its lanes -- and env_lp3_kernel finishes
-                    // and integrates them, one per lane.  Nothing of the 3-D LP runs here.
+                    // and integrates them, one per lane.  Nothing of the 3-D LP runs here unless a lane's slot falls
+                    // past the bounded sub-queue: those lanes take the in-place code below (ONE call site for both
+                    // uses: a second inlined copy cost 28 registers and a wavefront of occupancy).
                     const bool need = fail_ < nl_;
                     const unsigned long long m = __ballot(need);
+                    bool turned_away = false;
                     if (m != 0ull) {
                         const Lp3Queue q = lp3_queue_view(p.out.lp3_queue, p.E, NT);
                         const int sub = (int)((blockIdx.x * (BLOCK / 64) + wave) & (kLp3Queues - 1));
@@ -249,21 +253,28 @@ __device__ __forceinline__ void env_step_body(const StepParams &p)
                         int base = 0;
                         if (lane == first) base = atomicAdd(q.count(sub), __popcll(m));
                         base = __shfl(base, first);
-                        if (need) {
+                        const int slot_q = base + __popcll(m & ((1ull << lane) - 1ull));
+                        if (need && slot_q < (int)q.subcap) {
                             deferred = true;
-                            qidx = (int)(sub * q.subcap) + base + __popcll(m & ((1ull << lane) - 1ull));
+                            qidx = (int)(sub * q.subcap) + slot_q;
                             q.hdr[qidx] = make_int4((int)a, nl_ | (fail_ << 8), __float_as_int((float)attr.y), 0);
                             q.res[qidx] = make_float2(ox, oy);
 #pragma unroll
                             for (int k2 = 0; k2 < NLK; ++k2) q.line[(long)k2 * q.cap + qidx] = Lnat[k2];
                         }
+                        turned_away = need && !deferred;
                     }
-                } else if constexpr (kCoopLp3) {
-                    lp_fail = fail_; lp_nl = nl_;
+                    solve_here = __ballot(turned_away) != 0ull;            // wave-uniform
+                    if (deferred) fail_ = nl_;                             // parked: nothing left to solve in this lane
+                }
+                if (solve_here) {
+                    if constexpr (kCoopLp3) {
+                        lp_fail = fail_; lp_nl = nl_;
 #pragma unroll
-                    for (int k2 = 0; k2 < NLK; ++k2) Lk[k2] = Lnat[k2];        // the wavefront finishes them together below
-                } else {
-                    lp3_static<NLK>(Lnat, nl_, fail_, (float)attr.y, ox, oy);
+                        for (int k2 = 0; k2 < NLK; ++k2) Lk[k2] = Lnat[k2];    // the wavefront finishes them together below
+                    } else {
+                        lp3_static<NLK>(Lnat, nl_, fail_, (float)attr.y, ox, oy);
+                    }
                 }
             } else {
                 GroupCand cand{sAgF, sRadF, make_float4(0, 0, 0, 0), 0.f, gbase, h, N - 1};
@@ -285,7 +296,8 @@ __device__ __forceinline__ void env_step_body(const StepParams &p)
     }
 
     if constexpr (kCoopLp3) {
-        if (!p.lp3_defer) {
+        // (with a queue: only the lanes a full sub-queue turned away -- wave-uniform, all lanes take part)
+        if (!p.lp3_defer || __ballot(lp_fail < lp_nl) != 0ull) {
             CoopLds &coop = reinterpret_cast<CoopLds *>(sRobRadF + BLOCK)[wave];
             lp3_wave_coop<NLK>(coop, Lk, lp_nl, lp_fail, (float)attr.y, ox, oy);      // every lane of the wavefront
         }
@@ -500,7 +512,8 @@ __global__ __launch_bounds__(256) void env_lp3_kernel(const StepParams p, const 
 {
     const Lp3Queue q = lp3_queue_view(p.out.lp3_queue, p.E, p.N);
     const int sub = blockIdx.x & (kLp3Queues - 1), rep = blockIdx.x / kLp3Queues;
-    const int count = __atomic_load_n(q.count(sub), __ATOMIC_RELAXED);
+    const int taken = __atomic_load_n(q.count(sub), __ATOMIC_RELAXED);
+    const int count = taken < (int)q.subcap ? taken : (int)q.subcap;      // slots past subcap were solved in place
     const long qbase = (long)sub * q.subcap;
     const double dt = p.cfg.time_step;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

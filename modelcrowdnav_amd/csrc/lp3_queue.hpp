@@ -26,6 +26,9 @@
 
 namespace mcn {
 
+#ifndef MCN_LP3_CAP_DIV
+#define MCN_LP3_CAP_DIV 2
+#endif
 constexpr int kLp3Queues = 256;
 constexpr long kLp3Header = 66560;
 
@@ -40,12 +43,21 @@ struct Lp3Queue {
     __host__ __device__ __forceinline__ int *done() const { return reinterpret_cast<int *>(base + 65536); }
 };
 
-// entries one sub-queue must hold in the worst case: the wavefronts mapped to it (every 256th of the grid, up to three
-// idle ones from rounding the grid to workgroups of four) x 64 lanes
+// entries of one sub-queue.  The worst case -- every lane of every wavefront mapped to it (every 256th of the grid, up to
+// three idle ones from rounding the grid to workgroups of four) parks a problem -- is 64 per wavefront: 527 MB for
+// 2^18 envs x 10 humans, three times the env state, for a queue that 0.9-3.7 % of the humans use on average.  Bounded
+// (round 4) to 1 / MCN_LP3_CAP_DIV of that, at least one wavefront's worth: a lane whose slot falls at or past subcap
+// solves its 3-D LP in place instead (same arithmetic, same bits), the counter may run past subcap and env_lp3_kernel
+// takes min(count, subcap) entries -- every slot below subcap was handed to exactly one lane, which filled it.
+// Half, not less: the need comes in bursts (the steps in which a circle crossing meets in the middle) and a sub-queue
+// sees the wavefronts of one residue class: measured at 2^18 x 10, a step takes 299 us with 1/1 and 1/2, 302 with 1/4,
+// 318 with 1/8 of the worst case (in-place solving is what the queue exists to avoid).
 __host__ __device__ __forceinline__ long lp3_subcap(long E, int N)
 {
     const long waves = (E + (64 / N) - 1) / (64 / N) + 3;
-    return (waves + kLp3Queues - 1) / kLp3Queues * 64;
+    const long worst = (waves + kLp3Queues - 1) / kLp3Queues * 64;
+    const long bounded = (worst / MCN_LP3_CAP_DIV + 63) / 64 * 64;
+    return bounded < 64 ? 64 : bounded;
 }
 
 __host__ __device__ __forceinline__ long lp3_lines_offset(long cap) { return (kLp3Header + cap * 28 + 15) & ~15L; }

@@ -391,6 +391,9 @@ constexpr int kStageBuf = kStageFloat4 + kStageBias;
 #ifndef MCN_X3_WHATIF
 #define MCN_X3_WHATIF 0     // timing-only what-if bits (profiles/r04_sarl_x3_whatif.txt); any non-zero value computes garbage
 #endif
+#ifndef MCN_DMA_SKIP_EMPTY
+#define MCN_DMA_SKIP_EMPTY 1
+#endif
 #ifndef MCN_LEAN_DMA
 #define MCN_LEAN_DMA 1
 #endif
@@ -413,7 +416,8 @@ __device__ __forceinline__ DmaLane dma_lane(int tid)
     return {static_cast<unsigned>(t) * 16u, t & ~63};
 }
 template <int MAX_ROUNDS>
-__device__ __forceinline__ void dma_rows(const float4 *base, int first, int n, float4 *dst, const DmaLane &L)
+__device__ __forceinline__ void dma_rows(const float4 *base, int first, int n, float4 *dst, const DmaLane &L,
+                                         int k0 = 0, int k1 = MAX_ROUNDS)
 {
     // rows base[first .. first + n); the row offset goes into the VGPR offset (one v_add per instruction, wrapping
     // unsigned so that it cannot be split off again): a scalar base per round would cost an SGPR pair per round and
@@ -421,9 +425,14 @@ __device__ __forceinline__ void dma_rows(const float4 *base, int first, int n, f
 #pragma unroll
     for (int k = 0; k < MAX_ROUNDS; ++k) {
         const int left = n - k * kStageThreads;            // rows from this round's first to the end
-        if (left > 0) {                                    // wave-uniform (compile-time at the call sites)
+        if (left > 0 && k >= k0 && k < k1) {               // wave-uniform (compile-time at the call sites)
             unsigned off = L.off;
-            if (left < kStageThreads) off = off < (left - 1) * 16u ? off : (left - 1) * 16u;
+            if (left < kStageThreads) {
+                // the round that straddles the end: wavefronts wholly past it issue nothing (a piece costs its issue
+                // slot whatever it moves), the one across it clamps
+                if (MCN_DMA_SKIP_EMPTY && __builtin_amdgcn_readfirstlane(L.wave_base) >= left) continue;
+                off = off < (left - 1) * 16u ? off : (left - 1) * 16u;
+            }
             off += static_cast<unsigned>(first + k * kStageThreads) * 16u;
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(base) + off),
@@ -601,6 +610,9 @@ struct X3 { bf16x8 hi, mid, lo; };
 #endif
 // scheduling fences around the MFMA groups of an x3 layer: 0 = nothing moves across (the split / ReLU blocks of one
 // wavefront then run between its MFMA groups and overlap the OTHER wavefront's MFMAs), 6 = vector / scalar ALU work may
+#ifndef MCN_X3_DMA_SPREAD
+#define MCN_X3_DMA_SPREAD 1
+#endif
 #ifndef MCN_X3_FENCE
 #define MCN_X3_FENCE 0
 #endif
@@ -761,6 +773,27 @@ __device__ __forceinline__ void dense_flow_x3(const X3 (&in)[KB], const f32x4 *i
         if (c + 1 < NCH) stage(c + 1);
         else if (next.n_w > 0) flow_stage_first(F, next, (F.parity + NCH) & 1);
     };
+    // part j of `parts` of the same request (MCN_X3_DMA_SPREAD > 1: the rounds of a chunk's DMA spread over its first
+    // groups instead of one burst behind the first MFMA)
+    auto request_part = [&](int c, int j, int parts) {
+        if (MCN_X3_WHATIF & 2) return;
+        const DmaLane L = dma_lane(F.tid);
+        if (c + 1 < NCH) {
+            float4 *dst = bufp[(c + 1) & 1];
+            const int rows = TOTAL - (c + 1) * CH < CH ? TOTAL - (c + 1) * CH : CH;
+            const int brows = HAS_INIT ? 0 : (NT * 64 - (c + 1) * BCH < BCH ? NT * 64 - (c + 1) * BCH : BCH);
+            const int rw = (rows + kStageThreads - 1) / kStageThreads, rb = (brows + kStageThreads - 1) / kStageThreads;
+            const int k0 = j * (rw + rb) / parts, k1 = (j + 1) * (rw + rb) / parts;
+            dma_rows<PER>(wf, (c + 1) * CH, rows, dst, L, k0, k1 < rw ? k1 : rw);
+            if (!HAS_INIT) dma_rows<BPER>(bf, (c + 1) * BCH, brows, dst + BOFF, L, k0 - rw, k1 - rw);
+        } else if (next.n_w > 0) {
+            float4 *dst = F.buf + ((F.parity + NCH) & 1) * kStageBuf;
+            const int rw = (next.n_w + kStageThreads - 1) / kStageThreads, rb = (next.n_b + kStageThreads - 1) / kStageThreads;
+            const int k0 = j * (rw + rb) / parts, k1 = (j + 1) * (rw + rb) / parts;
+            dma_rows<kStageFloat4 / kStageThreads>(next.w, 0, next.n_w, dst, L, k0, k1 < rw ? k1 : rw);
+            dma_rows<3>(next.b, 0, next.n_b, dst + next.b_at, L, k0 - rw, k1 - rw);
+        }
+    };
     issue(std::integral_constant<int, 0>{});
     f32x4 a = {0, 0, 0, 0};
     float4 initv[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
@@ -793,7 +826,13 @@ __device__ __forceinline__ void dense_flow_x3(const X3 (&in)[KB], const f32x4 *i
                     // group's reads, and at a chunk's first group the DMA of what follows the chunk
                     __builtin_amdgcn_sched_barrier(MCN_X3_FENCE);
                     if constexpr (g + 1 < NG) { if (!(MCN_X3_WHATIF & 4)) issue(std::integral_constant<int, g + 1>{}); }
-                    if constexpr (at_first && !at_last) request_next(c);
+                    if constexpr (MCN_X3_DMA_SPREAD <= 1) {
+                        if constexpr (at_first && !at_last) request_next(c);
+                    } else if constexpr (!at_last) {
+                        constexpr int gn = Geo::groups_in(c), j = g - Geo::first_of(c);
+                        constexpr int parts = gn - 1 < MCN_X3_DMA_SPREAD ? gn - 1 : MCN_X3_DMA_SPREAD;
+                        if constexpr (j < parts) request_part(c, j, parts);
+                    }
                     __builtin_amdgcn_sched_barrier(MCN_X3_FENCE);
                 }
                 a = X3_MFMA(wh, in[m].lo, a, 0, 0, 0);

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
     // chunk of every layer) would otherwise be hoisted out of this loop and live -- and spill -- across it
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    const WeightStage S{s_stage, tid};
+    const WeightStage S{s_stage, tid}; (void)S;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;

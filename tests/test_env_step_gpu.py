@@ -94,6 +94,42 @@ def test_step_matches_oracle_bitexact(N, visible, randomize, update, kernel, tun
         H.assert_state_equal(H.download(env), st, what="lookahead must not mutate")
 
 
+@pytest.mark.parametrize("N,visible,block", [(10, False, 256), (10, False, 64), (6, True, 256), (8, False, 64)])
+@pytest.mark.parametrize("update", [True, False])
+def test_full_lp3_queue_turns_lanes_back_to_solving_in_place(N, visible, block, update, tuning):
+    """The deferred-3-D-LP queue holds half of the worst case (lp3_queue.hpp).  Crowds packed into overlapping
+    discs send most humans into the 3-D LP -- far more than the sub-queues hold: the lanes past a sub-queue's capacity
+    finish their problem in the step kernel (register-resident or wavefront-cooperative, by workgroup shape), the rest
+    are parked, and every output is still the oracle's, bit for bit."""
+    from modelcrowdnav_amd import _hip
+    tuning(quad_max_envs=0)
+    tuning(lp3_defer=1)
+    tuning(step_block=block)
+    rng = np.random.RandomState(31 + N)
+    E = 8192 + 37
+    env = H.make_vec_env(E, N, robot_visible=visible)
+    st = H.random_state(rng, E, N, randomize=True)
+    # every env's humans inside a disc of radius 0.45 around one point: every pair overlaps
+    cx, cy = rng.uniform(-3, 3, (E, 1)), rng.uniform(-3, 3, (E, 1))
+    ang, d = rng.uniform(0, 2 * np.pi, (E, N)), rng.uniform(0.0, 0.45, (E, N))
+    st.hpx[:], st.hpy[:] = cx + d * np.cos(ang), cy + d * np.sin(ang)
+    sp, aa = rng.uniform(0, 1, E), rng.uniform(0, 2 * np.pi, E)
+    cport.lp3_entries(reset=True)
+    got, ref, ref_st = _step_both(env, st, sp * np.cos(aa), sp * np.sin(aa), update)
+    waves = (E + 64 // N - 1) // (64 // N) + 3
+    subcap = max(64, ((waves + 255) // 256 * 64 // 2 + 63) // 64 * 64)      # lp3_queue.hpp: lp3_subcap
+    assert int(_hip.lib.mcn_env_lp3_queue_bytes(E, N)) < 256 * subcap * (28 + 16 * N) + (1 << 17)
+    assert cport.lp3_entries() > 1.2 * 256 * subcap, (cport.lp3_entries(), 256 * subcap)
+    for k in ref:
+        assert np.array_equal(got[k], ref[k]), k
+    if update:
+        H.assert_state_equal(H.download(env), ref_st, what="N=%d" % N)
+    # the queue's counters were reset by the finish kernel: a second step from the same state gives the same bits
+    got2, _, _ = _step_both(env, st, sp * np.cos(aa), sp * np.sin(aa), update)
+    for k in ref:
+        assert np.array_equal(got2[k], ref[k]), k
+
+
 def test_given_velocity_and_linear_modes():
     rng = np.random.RandomState(5)
     E, N = 1000, 5

@@ -412,3 +412,56 @@ def test_bf16x3_layers_agree_with_the_float32_mfma_layers(N):
     top2 = torch.topk(v_f32, 2, dim=1).values
     assert bool((same | ((top2[:, 0] - top2[:, 1]) < 2 * d)).all())
     assert same.float().mean().item() > 0.99
+
+
+@pytest.mark.parametrize("weights", ["seed 9", "g17"])
+def test_network_error_against_a_float64_evaluation(weights, golden_dir):
+    """How accurate is "float32-accurate"?  The value network evaluated in float64 on the same float32 inputs and
+    weights is the yardstick: the torch float32 evaluation (what the reference runs), the float32 MFMA layers and the
+    bf16x3 layers are three different roundings of it.  The bf16x3 path -- six of nine piece products, float32
+    accumulation -- must not be further from the float64 result than twice the float32 reference's own distance
+    (+ 5e-7); two weight sets (this package's default initialisation, the reference-side network recorded in g17)."""
+    import torch
+    from modelcrowdnav_amd import _hip
+    N, E = 5, 256
+    rng = np.random.RandomState(11)
+    if weights == "g17":
+        g = np.load(os.path.join(golden_dir, "g17_sarl_unicycle.npz"))
+        pol = _policy(weights=_weights(g, "w__"))
+    else:
+        pol = _policy(seed=9)
+    env = H.make_vec_env(E, N)
+    st = H.random_state(rng, E, N, randomize=True)
+    H.upload(env, st)
+    _, _, v_x3 = pol.predict_batch(env, want_values=True)
+    v_x3 = v_x3.cpu().numpy().copy()
+    with _hip.tuned(sarl_x3=0):
+        _, _, v_f32 = pol.predict_batch(env, want_values=True)
+        v_f32 = v_f32.cpu().numpy().copy()
+    w32 = {k: v.detach().cpu() for k, v in pol.model.state_dict().items()}
+    w64 = {k: v.double() for k, v in w32.items()}
+    table, dt = pol._action_table, 0.25
+    err = dict(x3=0.0, f32_mfma=0.0, torch_f32=0.0)
+    for e in range(0, E, 8):
+        reached = float(np.linalg.norm((st.rpy[e] - st.rgy[e], st.rpx[e] - st.rgx[e]))) < st.rr[e]
+        if reached:
+            continue
+        nxt = np.stack([st.hpx[e] + st.hvx[e] * dt, st.hpy[e] + st.hvy[e] * dt, st.hvx[e], st.hvy[e], st.hr[e]], 1)
+        rows = np.zeros((len(table), N, 14))
+        rows[:, :, 0] = (st.rpx[e] + table[:, 0] * dt)[:, None]; rows[:, :, 1] = (st.rpy[e] + table[:, 1] * dt)[:, None]
+        rows[:, :, 2] = table[:, 0][:, None]; rows[:, :, 3] = table[:, 1][:, None]
+        rows[:, :, 4] = st.rr[e]; rows[:, :, 5] = st.rgx[e]; rows[:, :, 6] = st.rgy[e]; rows[:, :, 7] = 1.0
+        rows[:, :, 9:] = nxt[None]
+        feats = pyref.rotate(torch.from_numpy(rows.reshape(-1, 14)).float()).view(len(table), N, 13)
+        truth = pyref.sarl_forward(w64, feats.double())[0].numpy()
+        ref32 = pyref.sarl_forward(w32, feats)[0].double().numpy()
+        rew = np.array([pyref.lookahead_reward(rows[a, 0, 0], rows[a, 0, 1], st.rr[e], st.rgx[e], st.rgy[e],
+                                               [(h[0], h[1], h[4]) for h in nxt], dt) for a in range(len(table))])
+        disc = 0.9 ** (dt * 1.0)
+        err["x3"] = max(err["x3"], float(np.abs((v_x3[e] - rew) / disc - truth).max()))
+        err["f32_mfma"] = max(err["f32_mfma"], float(np.abs((v_f32[e] - rew) / disc - truth).max()))
+        err["torch_f32"] = max(err["torch_f32"], float(np.abs(ref32 - truth).max()))
+    print("SARL network error vs float64 (weights: %s): %s" % (weights, ", ".join("%s %.2e" % kv for kv in err.items())))
+    assert err["torch_f32"] > 0
+    assert err["x3"] <= 2 * err["torch_f32"] + 5e-7, err
+    assert err["f32_mfma"] <= 2 * err["torch_f32"] + 5e-7, err

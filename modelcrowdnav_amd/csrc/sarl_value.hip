@@ -46,13 +46,16 @@
 #ifndef MCN_X3_INLOOP_SPLIT
 #define MCN_X3_INLOOP_SPLIT 0
 #endif
+#ifndef MCN_X3_M2A_EARLY
+#define MCN_X3_M2A_EARLY 1
+#endif
 #ifndef MCN_X3_GAT_MEM
 #define MCN_X3_GAT_MEM 0
 #endif
 
 namespace mcn {
 
-constexpr bool kX3In = MCN_X3_INLOOP_SPLIT != 0, kX3GatMem = MCN_X3_GAT_MEM != 0;
+constexpr bool kX3In = MCN_X3_INLOOP_SPLIT != 0, kX3GatMem = MCN_X3_GAT_MEM != 0, kM2aEarly = MCN_X3_M2A_EARLY != 0;
 // a layer's output tiles -> the next layer's input blocks, after the layer (when it did not split them itself)
 template <int NT, int NB>
 __device__ __forceinline__ void split_after(const f32x4 (&t)[NT], X3 (&o)[NB])
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
         X3 gp[B100];
 #pragma unroll
         for (int m = 0; m < B100; ++m) gp[m] = split8(gsum[2 * m], 2 * m + 1 < T100 ? gsum[2 * m + 1] : zero4);
-        dense_flow_x3<B100, T100, false, false>(gp, nullptr, gat, no4, p.x.w_atg, reinterpret_cast<const float4 *>(p.f.b_ata), F, lane, d_ata);
+        dense_flow_x3<B100, T100, false, false>(gp, nullptr, gat, no4, p.x.w_atg, reinterpret_cast<const float4 *>(p.f.b_ata), F, lane, kM2aEarly ? d_m2a : d_ata);
         if (kX3GatMem) {
             // parked in the workspace: the per-human attention.0 layers fetch it tile by tile as their accumulator start
             // (28 registers that would otherwise be live across the whole second pass)
@@ -379,10 +382,17 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
                 dst[m].lo = __builtin_bit_cast(bf16x8, ws[(i * WSR + 3 * m + 2) * 64 + lane]);
             }
         };
+        f32x4 m1[T100];
         if constexpr (USE_X3) {
             X3 hp[B100];
             load_pieces(hp);
             SARL_PHASE(6);              // workspace load
+            if constexpr (kM2aEarly) {
+                // mlp2.0 of this human FIRST, while its mlp1 pieces are in registers for attention.0 anyway: its 28
+                // output registers wait for the score instead of the 12 KiB of pieces being read a second time
+                dense_flow_x3<B100, T100, true, false, false, false>(hp, nullptr, m1, no4, p.x.w_m2a, reinterpret_cast<const float4 *>(p.f.b_m2a),
+                                                                    F, lane, d_ata);
+            }
             X3 ap[B100], bp[B100];
             dense_flow_x3<B100, T100, true, true, kX3In, kX3GatMem>(hp, kX3GatMem ? reinterpret_cast<const f32x4 *>(ws + (N * WSR) * 64 + lane) : gat,
                                                                     a1, ap, p.x.w_ata, nullptr, F, lane, d_atb);
@@ -391,7 +401,8 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
             dense_flow_x3<B100, T100, true, false, kX3In>(ap, nullptr, a2, bp, p.x.w_atb, reinterpret_cast<const float4 *>(p.f.b_atb), F, lane, d_atc);
             if (!kX3In) split_after(a2, bp);
             SARL_PHASE(8);              // attention.2
-            dense_flow_x3<B100, T1, false, false>(bp, nullptr, sc, no1, p.x.w_atc, reinterpret_cast<const float4 *>(p.f.b_atc), F, lane, d_m2a);
+            dense_flow_x3<B100, T1, false, false>(bp, nullptr, sc, no1, p.x.w_atc, reinterpret_cast<const float4 *>(p.f.b_atc), F, lane,
+                                                  kM2aEarly ? (i + 1 < N ? d_m2a : d_m2b) : d_m2a);
         } else {
 #pragma unroll
         for (int t = 0; t < T100; ++t) {
@@ -412,8 +423,12 @@ __global__ __launch_bounds__(kSarlWaves * 64, kSarlWaves >= 8 ? 1 : 2) void sarl
         if (p.attention && valid && q == 0) p.attention[pair * N + i] = es;   // normalised by the host view
         denom += es;
         SARL_PHASE(10);                 // exp, attention output
-        f32x4 m1[T100];
-        if constexpr (USE_X3) {
+        if constexpr (USE_X3 && kM2aEarly) {
+#pragma unroll
+            for (int t = 0; t < T100; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) racc[t][r] = i < ne ? __builtin_fmaf(es, m1[t][r], racc[t][r]) : racc[t][r];
+        } else if constexpr (USE_X3) {
             X3 hp[B100];
             load_pieces(hp);            // (read again rather than kept: 48 registers across the attention layers)
             auto pool = [&](int n, const f32x4 &v) {        // weighted sum of the hidden activations, tile by tile

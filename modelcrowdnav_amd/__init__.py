@@ -7,4 +7,4 @@
 Host code is Python on PyTorch-ROCm (device memory, streams, torch.distributed); every
 hot op is a HIP kernel reached through the C ABI.  There is no CPU fallback.
 """
-__version__ = "0.3.0"
+__version__ = "0.4.0"

@@ -196,9 +196,9 @@ static int fill_step_params(mcn::StepParams &p, const mcn_env_cfg *cfg, const mc
 extern "C" {
 
 #ifdef MCN_DIAG
-const char *mcn_version(void) { return "modelcrowdnav_amd 0.3 (gfx950) DIAGNOSTIC BUILD (time stamps)"; }
+const char *mcn_version(void) { return "modelcrowdnav_amd 0.4 (gfx950) DIAGNOSTIC BUILD (time stamps)"; }
 #else
-const char *mcn_version(void) { return "modelcrowdnav_amd 0.3 (gfx950)"; }
+const char *mcn_version(void) { return "modelcrowdnav_amd 0.4 (gfx950)"; }
 #endif
 
 int mcn_set_tuning(const mcn_tuning *t)

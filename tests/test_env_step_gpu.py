@@ -713,13 +713,16 @@ def test_config5_shape_32768x10_exact_and_shard_invariant():
     assert np.array_equal(env.rpos.cpu().numpy(), np.concatenate([s_.rpos.cpu().numpy() for s_ in shards], 0))
 
 
-def test_bench_kernel_attribution_matches_the_dispatcher():
+def test_bench_kernel_attribution_matches_the_dispatcher(tuning):
     """bench.expected_kernel() decides which profile rows (PMC traffic, SQ counters) a roofline entry is built from; it
     re-states the library's dispatch rules in Python.  Every launch shape bench.py reports is launched here once and the
-    family the dispatcher REALLY took (mcn_last_dispatch) must be the one bench names."""
+    family the dispatcher REALLY took (mcn_last_dispatch) must be the one bench names (with the library's own defaults:
+    a run of the suite under MCN_* overrides must not change what this test checks)."""
     torch = _torch()
     import bench
     from modelcrowdnav_amd import _hip
+    tuning(force_generic=0, quad_max_envs=-1, quad_split=-1, rollout_fused=-1, rollout_split=-1, step_block=-1,
+           pair_stream=-1, lp3_defer=-1)
     dev = torch.device("cuda", 0)
     for E, N, spl in [(4096, 5, 1), (4096, 5, 20), (4096, 5, 1000), (4096, 10, 1), (4096, 10, 500), (32768, 10, 1),
                       (1 << 16, 5, 1), (1 << 18, 10, 1)]:

@@ -397,9 +397,9 @@ def test_bf16x3_layers_agree_with_the_float32_mfma_layers(N):
     pol = _policy(seed=5)
     env = H.make_vec_env(E, N)
     H.upload(env, H.random_state(rng, E, N, randomize=True))
-    assert _hip.get_tuning().sarl_x3 != 0
-    _, best_x3, v_x3 = pol.predict_batch(env, want_values=True)
-    v_x3, best_x3 = v_x3.clone(), best_x3.clone()
+    with _hip.tuned(sarl_x3=1):
+        _, best_x3, v_x3 = pol.predict_batch(env, want_values=True)
+        v_x3, best_x3 = v_x3.clone(), best_x3.clone()
     with _hip.tuned(sarl_x3=0):
         _, best_f32, v_f32 = pol.predict_batch(env, want_values=True)
         v_f32, best_f32 = v_f32.clone(), best_f32.clone()
@@ -433,8 +433,9 @@ def test_network_error_against_a_float64_evaluation(weights, golden_dir):
     env = H.make_vec_env(E, N)
     st = H.random_state(rng, E, N, randomize=True)
     H.upload(env, st)
-    _, _, v_x3 = pol.predict_batch(env, want_values=True)
-    v_x3 = v_x3.cpu().numpy().copy()
+    with _hip.tuned(sarl_x3=1):
+        _, _, v_x3 = pol.predict_batch(env, want_values=True)
+        v_x3 = v_x3.cpu().numpy().copy()
     with _hip.tuned(sarl_x3=0):
         _, _, v_f32 = pol.predict_batch(env, want_values=True)
         v_f32 = v_f32.cpu().numpy().copy()

@@ -93,6 +93,72 @@ __global__ __launch_bounds__(256, 2) void k(const float4 *__restrict__ table, in
     if (lane == 0) cyc[blockIdx.x * 4 + (tid >> 6)] = t1 - t0;
 }
 
+// The alternative shape: ONE wavefront per SIMD carrying TWO 16-pair tiles (each A piece read once feeds 12 MFMAs on
+// two independent accumulators), one 4-wavefront workgroup per CU: pieces, ds_reads and barriers per MFMA all halved.
+// DMA = 0: no weight movement, 1: 6 pieces per wavefront and chunk (the same 24-KiB chunk now serves 8 tiles).
+template <int DMA>
+__global__ __launch_bounds__(256, 1) void k2(const float4 *__restrict__ table, int table_rows, float *out,
+                                            unsigned long long *cyc, int chunks)
+{
+    __shared__ float4 stage[2][kChunkRows + 256];
+    __shared__ float4 pad_to_one_workgroup_per_cu[4096];         // 64 KiB more: two workgroups do not fit a CU
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_base = tid & ~63;
+    bf16x8 b0, b1;
+    for (int i = 0; i < 8; ++i) { b0[i] = (__bf16)(0.5f + i * 1e-2f + lane * 1e-3f); b1[i] = (__bf16)(0.25f + i * 2e-2f + lane * 1e-3f); }
+    for (int i = tid; i < 2 * (kChunkRows + 256); i += 256) (&stage[0][0])[i] = make_float4(1.f, 2.f, 3.f, (float)i);
+    if (tid == 0) pad_to_one_workgroup_per_cu[blockIdx.x & 4095] = make_float4(0, 0, 0, 0);
+    __syncthreads();
+    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    unsigned row = (blockIdx.x * 977u) % (unsigned)(table_rows - kChunkRows);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int c = 0; c < chunks; ++c) {
+        float4 *dst = stage[(c + 1) & 1];
+        const float4 *src = stage[c & 1];
+        const float4 *from = table + row;
+        row += kChunkRows;
+        if (row >= (unsigned)(table_rows - kChunkRows)) row -= (unsigned)(table_rows - kChunkRows);
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+            const float4 w0 = src[(g * 192 + lane) % kChunkRows], w1 = src[(g * 192 + 64 + lane) % kChunkRows],
+                         w2 = src[(g * 192 + 128 + lane) % kChunkRows];
+            if (g == kGroups - 1) __syncthreads();
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2), b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2), b1, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (DMA && g == 0) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(from) +
+                                                                           (unsigned)((r * 256 + tid) * 16)),
+                        (__attribute__((address_space(3))) void *)(dst + r * 256 + wave_base), 16, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#define TWO(w) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), b0, acc0, 0, 0, 0); \
+               acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), b1, acc1, 0, 0, 0);
+            TWO(w0) TWO(w1) TWO(w1) TWO(w0) TWO(w0)
+#undef TWO
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * 256 + tid] = acc0[0] + acc0[1] + acc1[2] + acc1[3] + pad_to_one_workgroup_per_cu[tid].x;
+    if (lane == 0) cyc[blockIdx.x * 4 + (tid >> 6)] = t1 - t0;
+}
+
+template <int DMA> static double run2(const float4 *table, int rows, float *out, unsigned long long *cyc, int chunks)
+{
+    const int blocks = 256;
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(k2<DMA>, dim3(blocks), dim3(256), 0, 0, table, rows, out, cyc, chunks);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> c((size_t)blocks * 4);
+    hipMemcpy(c.data(), cyc, c.size() * 8, hipMemcpyDeviceToHost);
+    std::sort(c.begin(), c.end());
+    return (double)c[c.size() / 2] / chunks;
+}
+
 template <int MODE> static double run(const float4 *table, int rows, float *out, unsigned long long *cyc, int chunks)
 {
     const int blocks = 512;
@@ -122,5 +188,9 @@ int main()
     for (int m = 0; m < 6; ++m)
         printf("mode %d  %-55s %7.2f ticks per chunk  (+%.2f = %+.0f cycles per piece)\n", m, what[m], t[m], t[m] - t[0],
                (t[m] - t[0]) * 24.0 / (m == 5 ? 3 : 6) / 2.0);
+    const double u0 = run2<0>(table, rows, out, cyc, chunks), u1 = run2<1>(table, rows, out, cyc, chunks);
+    printf("# two tiles per wavefront, one wavefront per SIMD: the same 96 MFMAs per SIMD and chunk (ideal 1536)\n");
+    printf("two-tile, no weight movement                                  %7.2f ticks per chunk\n", u0);
+    printf("two-tile, 6 x global_load_lds_dwordx4 in one burst            %7.2f ticks per chunk  (+%.2f)\n", u1, u1 - u0);
     return 0;
 }

@@ -159,6 +159,91 @@ template <int DMA> static double run2(const float4 *table, int rows, float *out,
     return (double)c[c.size() / 2] / chunks;
 }
 
+// Where the two-wavefront loop itself loses its 0.67: the kernel's shape (mode 1) with one ingredient changed at a time.
+//   V = 1 no workgroup barrier, 2 no ds_reads (pieces stay in registers), 3 two accumulator chains per wavefront
+//   (alternating MFMAs, summed per chunk), 4 = 1 + 2 + 3, 5 = reads for group g + 1 issued behind group g's first MFMA
+//   (NOT comparable with the kernel's ring: here the next chunk's first reads come from the buffer the DMA is filling,
+//   so the compiler puts a vmcnt(0) right behind the burst; kept as a record of that trap)
+template <int V>
+__global__ __launch_bounds__(256, 2) void k3(const float4 *__restrict__ table, int table_rows, float *out,
+                                            unsigned long long *cyc, int chunks)
+{
+    __shared__ float4 stage[2][kChunkRows + 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_base = tid & ~63;
+    bf16x8 b;
+    for (int i = 0; i < 8; ++i) b[i] = (__bf16)(0.5f + i * 1e-2f + lane * 1e-3f);
+    for (int i = tid; i < 2 * (kChunkRows + 256); i += 256) (&stage[0][0])[i] = make_float4(1.f, 2.f, 3.f, (float)i);
+    __syncthreads();
+    f32x4 acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+    float4 w0 = stage[0][lane], w1 = stage[0][64 + lane], w2 = stage[0][128 + lane];
+    float4 n0 = w0, n1 = w1, n2 = w2;
+    unsigned row = (blockIdx.x * 977u) % (unsigned)(table_rows - kChunkRows);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int c = 0; c < chunks; ++c) {
+        float4 *dst = stage[(c + 1) & 1];
+        const float4 *src = stage[c & 1];
+        const float4 *from = table + row;
+        row += kChunkRows;
+        if (row >= (unsigned)(table_rows - kChunkRows)) row -= (unsigned)(table_rows - kChunkRows);
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+            if (V == 5) { w0 = n0; w1 = n1; w2 = n2; }
+            else if (V != 2 && V != 4) {
+                w0 = src[(g * 192 + lane) % kChunkRows]; w1 = src[(g * 192 + 64 + lane) % kChunkRows];
+                w2 = src[(g * 192 + 128 + lane) % kChunkRows];
+            }
+            if (g == kGroups - 1 && V != 1 && V != 4) __syncthreads();
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2), b, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (V == 5) {
+                const float4 *nsrc = g + 1 < kGroups ? src : dst;
+                const int ng = (g + 1) % kGroups;
+                n0 = nsrc[(ng * 192 + lane) % kChunkRows]; n1 = nsrc[(ng * 192 + 64 + lane) % kChunkRows];
+                n2 = nsrc[(ng * 192 + 128 + lane) % kChunkRows];
+            }
+            if (g == 0) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(from) +
+                                                                           (unsigned)((r * 256 + tid) * 16)),
+                        (__attribute__((address_space(3))) void *)(dst + r * 256 + wave_base), 16, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (V == 3 || V == 4) {
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), b, acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1), b, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1), b, acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), b, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), b, acc2, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), b, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1), b, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1), b, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), b, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0), b, acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * 256 + tid] = acc[0] + acc[1] + acc2[2] + acc2[3] + n0.x;
+    if (lane == 0) cyc[blockIdx.x * 4 + (tid >> 6)] = t1 - t0;
+}
+
+template <int V> static double run3(const float4 *table, int rows, float *out, unsigned long long *cyc, int chunks)
+{
+    const int blocks = 512;
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(k3<V>, dim3(blocks), dim3(256), 0, 0, table, rows, out, cyc, chunks);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> c((size_t)blocks * 4);
+    hipMemcpy(c.data(), cyc, c.size() * 8, hipMemcpyDeviceToHost);
+    std::sort(c.begin(), c.end());
+    return (double)c[c.size() / 2] / chunks;
+}
+
 template <int MODE> static double run(const float4 *table, int rows, float *out, unsigned long long *cyc, int chunks)
 {
     const int blocks = 512;
@@ -188,6 +273,13 @@ int main()
     for (int m = 0; m < 6; ++m)
         printf("mode %d  %-55s %7.2f ticks per chunk  (+%.2f = %+.0f cycles per piece)\n", m, what[m], t[m], t[m] - t[0],
                (t[m] - t[0]) * 24.0 / (m == 5 ? 3 : 6) / 2.0);
+    printf("# the kernel's shape (two wavefronts per SIMD, 6 pieces per chunk) with one ingredient changed at a time\n");
+    printf("as mode 1 (reads right before use)          %7.2f\n", run3<0>(table, rows, out, cyc, chunks));
+    printf("no workgroup barrier                        %7.2f\n", run3<1>(table, rows, out, cyc, chunks));
+    printf("no ds_reads                                 %7.2f\n", run3<2>(table, rows, out, cyc, chunks));
+    printf("two accumulator chains per wavefront        %7.2f\n", run3<3>(table, rows, out, cyc, chunks));
+    printf("all three                                   %7.2f\n", run3<4>(table, rows, out, cyc, chunks));
+    printf("reads one group ahead (the kernel's ring)   %7.2f\n", run3<5>(table, rows, out, cyc, chunks));
     const double u0 = run2<0>(table, rows, out, cyc, chunks), u1 = run2<1>(table, rows, out, cyc, chunks);
     printf("# two tiles per wavefront, one wavefront per SIMD: the same 96 MFMAs per SIMD and chunk (ideal 1536)\n");
     printf("two-tile, no weight movement                                  %7.2f ticks per chunk\n", u0);

@@ -130,6 +130,41 @@ def test_full_lp3_queue_turns_lanes_back_to_solving_in_place(N, visible, block, 
         assert np.array_equal(got2[k], ref[k]), k
 
 
+@pytest.mark.parametrize("E,N,mode", [(1 << 20, 5, "orca"), (1 << 22, 5, "orca"), (1 << 22, 5, "given"),
+                                      (1 << 20, 5, "given"), (1 << 18, 10, "orca")])
+def test_roofline_sweep_sizes_every_env_against_the_oracle(E, N, mode):
+    """The batches bench.py's `roofline_sweep` times (2^20 and 2^22 envs of 5 humans through the fused ORCA kernel and the
+    streaming pairwise kernel with non-temporal streams; 2^18 envs of 10 humans, where the dispatcher parks the 3-D LPs
+    in the bounded queue by itself): one step of EVERY env against the C oracle, every byte of state and outputs -- the
+    kernels that are measured at these sizes are the kernels that are right at these sizes (64-bit offsets, the
+    XCD-chunked grid, the last partial workgroup)."""
+    torch = _torch()
+    from modelcrowdnav_amd import _hip
+    rng = np.random.RandomState(E % 1000 + N)
+    E = E - 3                      # ragged against every tile size
+    env = H.make_vec_env(E, N)
+    st = H.random_state(rng, E, N, randomize=True)
+    sp, aa = rng.uniform(0, 1, E), rng.uniform(0, 2 * np.pi, E)
+    if mode == "given":
+        env.count_hh = False       # ModelCrowdSim.step: no human-human count (the streaming kernel's contract)
+        env.track_human_times = False
+        env.export_human_actions = False
+        gv = rng.uniform(-1, 1, (E, N, 2))
+        got, ref, ref_st = _step_both(env, st, sp * np.cos(aa), sp * np.sin(aa), True, cport.HUMANS_GIVEN, gv)
+        assert _hip.last_dispatch() == "env_pair_kernel"
+    else:
+        got, ref, ref_st = _step_both(env, st, sp * np.cos(aa), sp * np.sin(aa), True)
+        assert _hip.last_dispatch() == "env_step_kernel"
+    for k in ref:
+        if k == "human_act" and mode == "given":
+            continue
+        assert np.array_equal(got[k], ref[k]), k
+    fields = [f for f in H.STATE_FIELDS if not (mode == "given" and f == "human_times")]
+    H.assert_state_equal(H.download(env), ref_st, fields=fields, what="E=%d N=%d %s" % (E, N, mode))
+    del env
+    torch.cuda.empty_cache()
+
+
 def test_given_velocity_and_linear_modes():
     rng = np.random.RandomState(5)
     E, N = 1000, 5

@@ -466,3 +466,63 @@ def test_network_error_against_a_float64_evaluation(weights, golden_dir):
     assert err["torch_f32"] > 0
     assert err["x3"] <= 2 * err["torch_f32"] + 5e-7, err
     assert err["f32_mfma"] <= 2 * err["torch_f32"] + 5e-7, err
+
+
+@pytest.mark.parametrize("N", [5, 10])
+def test_benchmark_grid_every_pair_against_the_torch_reference(N):
+    """BASELINE configs 3 / 4 in full: all 4096 x 81 (env, action) values of one predict_batch against the torch-fp32
+    restatement of MultiHumanRL.predict (multi_human_rl.py:35-63: propagate, reward ladder, rotate, ValueNetwork.forward),
+    evaluated batched on the CPU -- not a sample of envs.  Bar 1e-5 on every value; the chosen action is the reference's
+    wherever its top two values are further apart than that."""
+    import torch
+    rng = np.random.RandomState(90 + N)
+    E, dt, gamma = 4096, 0.25, 0.9
+    pol = _policy(seed=4)
+    env = H.make_vec_env(E, N)
+    st = H.random_state(rng, E, N, randomize=True)
+    H.upload(env, st)
+    actions, best, values = pol.predict_batch(env, want_values=True)
+    torch.cuda.synchronize()
+    values, best = values.cpu().numpy(), best.cpu().numpy()
+    table = np.asarray(pol._action_table, np.float64)
+    A = len(table)
+    w = {k: v.detach().cpu() for k, v in pol.model.state_dict().items()}
+    # propagate (float64), one row per (env, action, human)
+    npx = st.rpx[:, None] + table[None, :, 0] * dt; npy = st.rpy[:, None] + table[None, :, 1] * dt          # [E, A]
+    hx, hy = st.hpx + st.hvx * dt, st.hpy + st.hvy * dt                                                      # [E, N]
+    rows = np.empty((E, A, N, 14))
+    rows[..., 0] = npx[:, :, None]; rows[..., 1] = npy[:, :, None]
+    rows[..., 2] = table[None, :, None, 0]; rows[..., 3] = table[None, :, None, 1]
+    rows[..., 4] = st.rr[:, None, None]; rows[..., 5] = st.rgx[:, None, None]; rows[..., 6] = st.rgy[:, None, None]
+    rows[..., 7] = 1.0; rows[..., 8] = 0.0
+    rows[..., 9] = hx[:, None, :]; rows[..., 10] = hy[:, None, :]
+    rows[..., 11] = st.hvx[:, None, :]; rows[..., 12] = st.hvy[:, None, :]; rows[..., 13] = st.hr[:, None, :]
+    # reward ladder (multi_human_rl.py:65-88), float64
+    d = np.sqrt((npx[:, :, None] - hx[:, None, :]) ** 2 + (npy[:, :, None] - hy[:, None, :]) ** 2) \
+        - st.rr[:, None, None] - st.hr[:, None, :]                                                          # [E, A, N]
+    coll = (d < 0).any(2)
+    dmin = d.min(2)
+    reach = np.sqrt((npx - st.rgx[:, None]) ** 2 + (npy - st.rgy[:, None]) ** 2) < st.rr[:, None]
+    rew = np.where(coll, -0.25, np.where(reach, 1.0, np.where(dmin < 0.2, (dmin - 0.2) * 0.5 * dt, 0.0)))
+    on_edge = (np.abs(d) < 1e-9).any(2) | (np.abs(dmin - 0.2) < 1e-9)        # a rung decided by the last bit: not compared
+    net = np.empty((E, A))
+    flat = torch.from_numpy(rows.reshape(E * A, N, 14))
+    with torch.no_grad():
+        for lo in range(0, E * A, 1 << 15):
+            chunk = flat[lo:lo + (1 << 15)].float()
+            B = chunk.shape[0]
+            feats = pyref.rotate(chunk.reshape(B * N, 14)).view(B, N, 13)
+            net.reshape(-1)[lo:lo + B] = pyref.sarl_forward(w, feats)[0].double().numpy()
+    ref = rew + gamma ** (dt * 1.0) * net
+    reached = np.sqrt((st.rpx - st.rgx) ** 2 + (st.rpy - st.rgy) ** 2) < st.rr       # policy.py:43-49: nothing evaluated
+    ok = ~reached[:, None] & ~on_edge
+    err = np.abs(values - ref)[ok]
+    print("SARL 4096 x 81 x %d: %d of %d values compared, max |value - reference| = %.3g" % (N, ok.sum(), E * A, err.max()))
+    assert ok.mean() > 0.9            # (random_state puts ~6 % of the robots on their goal: nothing is evaluated there)
+    assert err.max() <= TOL
+    moving = ~reached & ~on_edge.any(1)
+    top2 = np.sort(ref, 1)[:, -2:]
+    clear = moving & (top2[:, 1] - top2[:, 0] > 2 * TOL)
+    assert clear.sum() > E // 2
+    assert np.array_equal(best[clear], ref[clear].argmax(1))
+    assert np.all(best[reached] == -1)

@@ -99,10 +99,11 @@ def test_per_scene_pedestrian_counts(golden_dir):
             np.testing.assert_allclose(got[e, :n], want, rtol=0, atol=4 * TOL)
 
 
-def test_full_size_step_on_sampled_scenes(golden_dir):
+@pytest.mark.parametrize("cover", ["sample", "every scene"])
+def test_full_size_step_on_sampled_scenes(cover, golden_dir):
     """BASELINE config 4's shape (4096 scenes x 10 pedestrians: 5 120 pool-net work units, i.e. every workgroup of the
     persistent pool kernel walks its unit list twice) against the torch-fp32 restatement on a sample of the scenes
-    (scenes are independent of each other)."""
+    (scenes are independent of each other) and, one step, on every scene."""
     import torch
     from modelcrowdnav_amd.policy.world_model import VecSGANWorld
     g, gen = _gen(golden_dir, "p")
@@ -115,7 +116,9 @@ def test_full_size_step_on_sampled_scenes(golden_dir):
     world.init_constant_velocity(torch.from_numpy(pos).to(dev), torch.from_numpy(vel).to(dev))
     frames = [np.around(pos - vel * 0.25 * k, 4) for k in range(7, -1, -1)]
     sample = np.concatenate([np.arange(0, 8), rng.choice(E, 48, replace=False), np.arange(E - 8, E)])
-    for step in range(2):
+    if cover == "every scene":
+        sample = np.arange(E)
+    for step in range(2 if cover == "sample" else 1):
         pos = pos + vel * 0.25
         noise = rng.normal(0, 1, (E, 8)).astype(np.float32)
         got = world(torch.from_numpy(pos).to(dev), torch.from_numpy(noise).to(dev)).cpu().numpy()

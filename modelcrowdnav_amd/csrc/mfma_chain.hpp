@@ -605,14 +605,12 @@ __device__ __forceinline__ void dense_flow(const f32x4 (&in)[KT], const f32x4 *i
 // mcn_pack_x3: per (output tile, input block) three 16-byte pieces per lane.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct X3 { bf16x8 hi, mid, lo; };
-#ifndef MCN_X3_AHEAD
-#define MCN_X3_AHEAD 1
-#endif
-// scheduling fences around the MFMA groups of an x3 layer: 0 = nothing moves across (the split / ReLU blocks of one
-// wavefront then run between its MFMA groups and overlap the OTHER wavefront's MFMAs), 6 = vector / scalar ALU work may
+// a chunk's DMA rounds in one burst behind its first MFMA (1) or spread over its first groups (measured: no gain)
 #ifndef MCN_X3_DMA_SPREAD
 #define MCN_X3_DMA_SPREAD 1
 #endif
+// scheduling fences around the MFMA groups of an x3 layer: 0 = nothing moves across (the split / ReLU blocks of one
+// wavefront then run between its MFMA groups and overlap the OTHER wavefront's MFMAs), 6 = vector / scalar ALU work may
 #ifndef MCN_X3_FENCE
 #define MCN_X3_FENCE 0
 #endif

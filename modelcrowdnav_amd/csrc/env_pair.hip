@@ -49,6 +49,9 @@ constexpr int kPairDiscMax = 128;
 // 460-556 us; 65 536 envs (41 MB: the state of one step is still cached when the next one starts) 9.0 -> 9.3-10.1 us,
 // i.e. they only pay once the step's footprint no longer fits the memory-side cache.  Marking the per-env pieces and
 // outputs too loses the gain (141 us at 2^20): neighbouring wavefronts complete each other's partial lines in cache.
+#ifndef MCN_PAIR_NT_ALL
+#define MCN_PAIR_NT_ALL 0      // A/B: the per-env pieces and outputs non-temporal as well (round 3 at 2^20: loses; round 4 at 2^22: see DESIGN)
+#endif
 typedef double pair_d2v __attribute__((ext_vector_type(2)));
 template <bool NTMP> __device__ __forceinline__ double2 pair_ld(const double2 *ptr)
 {
@@ -117,12 +120,12 @@ __global__ __launch_bounds__(256) void env_pair_kernel(const StepParams p)
         src = h == 2 ? reinterpret_cast<const double2 *>(p.actions) : src;
         src = h >= 3 ? reinterpret_cast<const double2 *>(ro.state) : src;
         const long pi = h >= 3 ? 2 * eb + (h - 3) : eb;
-        if (h < 3 || (h < 5 && has_state)) piece = src[pi];
+        if (h < 3 || (h < 5 && has_state)) piece = (MCN_PAIR_NT_ALL && NTMP) ? pair_ld<true>(src + pi) : src[pi];
     }
     double small = 0;
     {
         const double *src = h == 0 ? p.st.rrad : p.st.gtime;
-        if (h < 2) small = src[eb];
+        if (h < 2) small = (MCN_PAIR_NT_ALL && NTMP) ? pair_ld<true>(src + eb) : src[eb];
     }
     if (MCN_PAIR_DISC == 0 && has_state) {
         const int len = ro.disc_len;
@@ -245,11 +248,11 @@ __global__ __launch_bounds__(256) void env_pair_kernel(const StepParams p)
         if (h == 2) { dst = reinterpret_cast<double2 *>(reinterpret_cast<double *>(p.out.rec) + 3 * eb); val = make_double2(rew, dmin); }
         if (h == 3) { dst = reinterpret_cast<double2 *>(ro.state) + 2 * eb; val = rs_lo; }
         if (h == 4) { dst = reinterpret_cast<double2 *>(ro.state) + 2 * eb + 1; val = rs_hi; }
-        if (active && (h < 3 || (h < 5 && has_state))) *dst = val;
+        if (active && (h < 3 || (h < 5 && has_state))) { if (MCN_PAIR_NT_ALL && NTMP) pair_st<true>(dst, val); else *dst = val; }
         double *d8 = p.st.gtime + eb;                                                     // h == 0
         double v8 = o_time;
         if (h == 1) { d8 = reinterpret_cast<double *>(p.out.rec) + 3 * eb + 2; v8 = ll2d((long long)tail); }
-        if (active && h < 2) *d8 = v8;
+        if (active && h < 2) { if (MCN_PAIR_NT_ALL && NTMP) __builtin_nontemporal_store(v8, d8); else *d8 = v8; }
     }
 }
 

@@ -72,7 +72,7 @@ constexpr int T13 = 1, T150 = 10, T100 = 7, T50 = 4, T56 = 5 /* pooled 4 + self 
 
 struct SarlFrags {
     // weight fragments [NT][KT][64 lanes] float4 and bias fragments [NT][64] float4, see pack order in
-    // modelcrowdnav_amd/policy/sarl_pack.py
+    // modelcrowdnav_amd/policy/sarl.py (_pack_plan, pack_value_network)
     const float4 *w_m1a, *b_m1a;   // 13 -> 150
     const float4 *w_m1b, *b_m1b;   // 150 -> 100
     const float4 *w_m2a, *b_m2a;   // 100 -> 100

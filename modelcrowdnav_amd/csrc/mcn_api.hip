@@ -189,7 +189,10 @@ static int fill_step_params(mcn::StepParams &p, const mcn_env_cfg *cfg, const mc
     const int envs_per_wave = 64 / (4 * N);
     const long quad_waves = envs_per_wave > 0 ? ((long)E + envs_per_wave - 1) / envs_per_wave : (1L << 40);
     p.quad_max_envs = tu.quad_max_envs >= 0 ? tu.quad_max_envs : (quad_waves <= 2800 ? E : 0);
-    p.quad_split = tu.quad_split >= 0 ? tu.quad_split : (quad_waves <= 512 ? 1 : 0);
+    // two cooperating wavefronts per env group while the doubled grid still finds idle issue slots; re-measured in round 4
+    // (5 humans, us per step without / with: 1024 envs 5.87 / 5.37, 2048 6.28 / 6.10, 4096 = 1366 wavefronts 7.20 / 6.95,
+    //  5120 7.60 / 8.01, 6144 7.71 / 8.68): up to ~1400 wavefronts (round 3's rule stopped at 512)
+    p.quad_split = tu.quad_split >= 0 ? tu.quad_split : (quad_waves <= 1400 ? 1 : 0);
     return MCN_OK;
 }
 
